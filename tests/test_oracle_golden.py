@@ -1,0 +1,121 @@
+"""CPU: the oracle (oracle/picnet_cpu.py) against the golden vectors produced by the imported
+reference (oracle/gen_golden.py).  This is what pins the oracle."""
+import torch
+import pytest
+
+from oracle import picnet_cpu as O
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def _params(sd):
+    return O.prepare_params(sd)
+
+
+def _check_block(fx, fn):
+    P = _params(fx["sd0"])
+    xs = [x.clone().requires_grad_(True) for x in fx["inputs"]]
+    y = fn(P, *xs)
+    torch.testing.assert_close(y, fx["out"], **TOL)
+    y.backward(fx["gout"])
+    for x, g in zip(xs, fx["gin"]):
+        if g.numel():
+            torch.testing.assert_close(x.grad, g, rtol=1e-4, atol=1e-6)
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(P[n].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
+    for k, v in fx["sd1"].items():  # SpectralNorm u/v state after one forward
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            torch.testing.assert_close(P[k], v, **TOL)
+
+
+def test_resblock_none(golden):
+    _check_block(golden("picnet_ops.pt")["resblock_none"], lambda P, x: O.res_block(P, "", x, "none") if False else O.res_block(_strip(P), "b", x, "none"))
+
+
+def _strip(P):
+    return {"b." + k: v for k, v in P.items()}
+
+
+@pytest.mark.parametrize("name,fn", [
+    ("resblock_down", lambda P, x: O.res_block(P, "b", x, "down")),
+    ("resblock_enc_opt", lambda P, x: O.res_block_encoder_optimized(P, "b", x)),
+    ("resblock_dec", lambda P, x: O.res_block_decoder(P, "b", x)),
+    ("output", lambda P, x: O.output_block(P, "b", x)),
+    ("auto_attn", lambda P, x: O.auto_attn(P, "b", x)),
+    ("ex_guided_att", lambda P, m, s, r: O.example_guided_attention(P, "b", m, s, r)),
+    ("ex_guided_att_out", lambda P, m, s, r: O.example_guided_attention(P, "b", m, s, r)),
+])
+def test_blocks(golden, name, fn):
+    fx = dict(golden("picnet_ops.pt")[name])
+    fx["sd0"] = {"b." + k: v for k, v in fx["sd0"].items()}
+    fx["sd1"] = {"b." + k: v for k, v in fx["sd1"].items()}
+    fx["gparams"] = {"b." + k: v for k, v in fx["gparams"].items()}
+    _check_block(fx, fn)
+
+
+def test_functional_pieces(golden):
+    fx = golden("picnet_ops.pt")
+    torch.testing.assert_close(O.gram_matrix(fx["gram"]["x"]), fx["gram"]["out"], **TOL)
+    for name, fn in (("style_loss", O.style_loss), ("contextual_loss", O.contextual_loss)):
+        x = fx[name]["x"].clone().requires_grad_(True)
+        l = fn(x, fx[name]["y"])
+        torch.testing.assert_close(l, fx[name]["out"], **TOL)
+        l.backward()
+        torch.testing.assert_close(x.grad, fx[name]["gx"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(O.lsgan(fx["lsgan"]["pred"], True), fx["lsgan"]["real"], **TOL)
+    torch.testing.assert_close(O.lsgan(fx["lsgan"]["pred"], False), fx["lsgan"]["fake"], **TOL)
+    torch.testing.assert_close(O.scale_img(fx["scale_img"]["mask"], (4, 4)), fx["scale_img"]["out"], **TOL)
+    torch.testing.assert_close(O.scale_img(fx["scale_img"]["mask"], (5, 7)), fx["scale_img"]["out_odd"], **TOL)
+    assert torch.equal(O.binarise_mask(fx["binarise"]["mask"]), fx["binarise"]["out"])  # bit-exact
+
+
+def test_two_training_steps(golden):
+    """Whole path: ReferenceFill forward + GANOptimizer.__call__ for two consecutive steps
+    (SpectralNorm u/v evolution, three D calls per step, Adam updates)."""
+    fx = golden("picnet_train_tiny.pt")
+    cfg = fx["config"]
+    PG, PD = O.prepare_params(fx["G_sd0"]), O.prepare_params(fx["D_sd0"])
+    PV = O.prepare_params(fx["V_sd"], frozen=True)
+    opt_g = torch.optim.Adam(O.unique_trainable(PG), lr=cfg["lr"])
+    opt_d = torch.optim.Adam(O.unique_trainable(PD), lr=cfg["lr"])
+    kw = dict(enc_layers=cfg["enc_layers"], enc_L=cfg["enc_L"], enc_z_nc=cfg["enc_z_nc"], dec_layers=cfg["dec_layers"],
+              dec_L=cfg["dec_L"], out_size=(cfg["out_size"],) * 2)
+
+    def d_fwd_patch():
+        pass
+
+    for step in range(2):
+        s = fx[f"step{step}"]
+        mask = O.binarise_mask(s["mask"])
+        gen = O.reference_fill_forward(PG, s["src"], s["ref"], mask, s["eps_p"], s["eps_q"], **kw)
+        torch.testing.assert_close(gen, s["gen"], rtol=1e-4, atol=1e-5)
+        PDl = {("" if not k else k): v for k, v in PD.items()}
+        g_loss, perc, sty, cx = _gen_losses(PDl, PV, s, gen, mask, cfg)
+        opt_g.zero_grad()
+        g_loss.backward()
+        for n, g in s["G_grads"].items():
+            torch.testing.assert_close(PG[n].grad, g, rtol=2e-3, atol=1e-7, msg=lambda m, n=n: f"G grad {n}: {m}")
+        opt_g.step()
+        d_loss = (O.lsgan(O.res_discriminator(PD, "", s["gt"], cfg["disc_layers"]), True)
+                  + O.lsgan(O.res_discriminator(PD, "", gen.detach(), cfg["disc_layers"]), False)) * 0.5
+        opt_d.zero_grad()
+        d_loss.backward()
+        for n, g in s["D_grads"].items():
+            torch.testing.assert_close(PD[n].grad, g, rtol=2e-3, atol=1e-7, msg=lambda m, n=n: f"D grad {n}: {m}")
+        opt_d.step()
+        for got, key in ((g_loss, "g_loss"), (d_loss, "d_loss"), (perc, "perc"), (sty, "style"), (cx, "cx")):
+            torch.testing.assert_close(got.detach(), s[key], rtol=1e-4, atol=1e-9)
+    for k, v in fx["G_sd2"].items():
+        torch.testing.assert_close(PG[k].detach(), v, rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f"G param {k}: {m}")
+    for k, v in fx["D_sd2"].items():
+        torch.testing.assert_close(PD[k].detach(), v, rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f"D param {k}: {m}")
+
+
+def _gen_losses(PD, PV, s, gen, mask, cfg):
+    import torch.nn.functional as F
+
+    g = O.lsgan(O.res_discriminator(PD, "", gen, cfg["disc_layers"]), True) * O.LAMBDA_G + F.l1_loss(gen, s["gt"])
+    perc = O.vgg_loss(PV, "", gen, s["gt"], "perceptual") * O.LAMBDA_PERC
+    sty = O.vgg_loss(PV, "", gen * (1 - mask).unsqueeze(1), s["src"], "style") * O.LAMBDA_STYLE
+    cx = O.vgg_loss(PV, "", gen * mask.unsqueeze(1), s["ref"] * mask.unsqueeze(1), "contextual") * O.LAMBDA_CX
+    return g + perc + sty + cx, perc, sty, cx
