@@ -1,0 +1,134 @@
+"""ctypes binding of the C ABI declared in include/fmi_hip.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no fallback:
+if the library is missing the product raises -- it never computes on the CPU or through ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfmi_hip.so")
+
+c_f = C.c_void_p  # device float*
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """fmi_conv_desc (include/fmi_hip.h)."""
+
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode")]
+
+
+class WeightEntry(C.Structure):
+    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("wf", vp), ("wt", vp), ("sigma", vp), ("rows", i32), ("C", i32), ("taps", i32), ("pad_", i32)]
+
+
+class WeightGradEntry(C.Structure):
+    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("sigma", vp), ("dwf", vp), ("dw", vp), ("rows", i32), ("C", i32), ("taps", i32), ("pad_", i32)]
+
+
+class AdamEntry(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64)]
+
+
+PD = C.POINTER(ConvDesc)
+
+# name -> argtypes (return type is always int status unless noted)
+SIGNATURES = {
+    "fmi_gemm_f32": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64, i64, f32, f32, vp, vp],
+    "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
+    "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],
+    "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, i32, i64, vp],
+    "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
+    "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "fmi_weight_prepare_f32": [vp, i32, vp],
+    "fmi_weight_grad_f32": [vp, i32, vp],
+    "fmi_softmax_rows_f32": [vp, vp, i64, i32, vp],
+    "fmi_softmax_rows_bwd_f32": [vp, vp, vp, i64, i32, vp],
+    "fmi_eltwise_f32": [i32, vp, vp, vp, i64, f32, vp],
+    "fmi_axpy_dev_f32": [vp, vp, vp, vp, i64, vp],
+    "fmi_dot_f32": [vp, vp, i64, f32, vp, vp],
+    "fmi_mask_binarise_i64": [vp, vp, i64, vp],
+    "fmi_mask_mul_f32": [vp, vp, vp, i64, i32, i32, vp],
+    "fmi_guide_blend_f32": [vp, vp, vp, vp, i64, i32, i32, vp],
+    "fmi_guide_blend_bwd_f32": [vp, vp, vp, vp, i64, i32, i32, vp],
+    "fmi_vae_sample_f32": [vp, vp, vp, vp, vp, i64, i32, vp],
+    "fmi_vae_sample_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "fmi_avgpool_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "fmi_avgpool_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "fmi_maxpool2_f32": [vp, vp, i32, i32, i32, i32, vp],
+    "fmi_maxpool2_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "fmi_instnorm_stats_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_apply_f32": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_bwd_reduce_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_bwd_apply_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_reduce_loss_f32": [i32, vp, vp, i64, f32, f32, vp, vp],
+    "fmi_reduce_loss_bwd_f32": [i32, vp, vp, i64, f32, f32, vp, vp, vp],
+    "fmi_gram_l1_bwd_f32": [vp, vp, vp, i32, i32, f32, vp, vp],
+    "fmi_cx_channel_mean_f32": [vp, vp, i64, i32, vp],
+    "fmi_cx_normalise_f32": [vp, vp, vp, vp, i64, i32, vp],
+    "fmi_cx_normalise_bwd_f32": [vp, vp, vp, vp, i64, i32, vp],
+    "fmi_cx_rows_f32": [vp, vp, vp, vp, i32, i32, f32, vp],
+    "fmi_cx_cols_f32": [vp, vp, vp, i32, i32, vp],
+    "fmi_cx_loss_f32": [vp, vp, vp, i32, i32, f32, vp],
+    "fmi_cx_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
+    "fmi_adam_step_f32": [vp, i32, i64, f32, f32, f32, f32, f32, i32, vp],
+    "fmi_upfirdn2d_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_fused_bias_act_f32": [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp],
+    "fmi_noise_bias_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
+}
+
+STATUS = {0: "ok", 1: "bad argument", 2: "unsupported shape/mode", 3: "kernel launch failed"}
+
+
+class FmiError(RuntimeError):
+    pass
+
+
+class Library:
+    """Loaded shared library with typed entry points; ``strict`` requires every declared symbol."""
+
+    def __init__(self, path: str = LIB_PATH, strict: bool = True):
+        if not os.path.exists(path):
+            raise FmiError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback."
+            )
+        self.path = path
+        self.cdll = C.CDLL(path)
+        self.missing = []
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+            setattr(self, name[4:], self._checked(name, fn))
+        if strict and self.missing:
+            raise FmiError(f"{path} lacks symbols {self.missing}")
+
+    @staticmethod
+    def _checked(name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise FmiError(f"{name} failed: {STATUS.get(rc, rc)}")
+
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def lib() -> Library:
+    global _LIB
+    if _LIB is None:
+        _LIB = Library()
+    return _LIB

@@ -1,0 +1,182 @@
+// Implicit-GEMM convolution family: forward, adjoint (= ConvTranspose2d forward / conv input gradient)
+// and weight gradient.  See include/fmi_hip.h for the contract and gemm_core.h for the machine mapping.
+#include "gemm_core.h"
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static int check_desc(const fmi_conv_desc* d) {
+  if (!d) return FMI_ERR_BAD_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 ||
+      d->pad < 0 || d->x_cstride < d->C || d->y_cstride < d->K)
+    return FMI_ERR_BAD_ARG;
+  const int pe = d->pad;
+  if (d->OH != (d->H + 2 * pe - d->kh) / d->stride + 1 || d->OW != (d->W + 2 * pe - d->kw) / d->stride + 1)
+    return FMI_ERR_BAD_ARG;
+  if (d->OH <= 0 || d->OW <= 0) return FMI_ERR_BAD_ARG;
+  if (d->pad_mode == 1 && (d->pad >= d->H || d->pad >= d->W)) return FMI_ERR_UNSUPPORTED;
+  if (d->pad_mode != 0 && d->pad_mode != 1) return FMI_ERR_UNSUPPORTED;
+  if ((int64_t)d->N * d->H * d->W > 0x7fffffffLL / 2 || (int64_t)d->kh * d->kw * d->C > 0x3fffffffLL) return FMI_ERR_UNSUPPORTED;
+  return FMI_OK;
+}
+
+// forward-geometry gather: anchors = output pixels of the conv
+static ConvGeom fwd_geom(const fmi_conv_desc* d, const float* x, int n_eff) {
+  ConvGeom g{};
+  g.N = n_eff; g.IH = d->H; g.IW = d->W; g.C = d->C; g.cstride = d->x_cstride;
+  g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
+  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = 1; g.xstep = 1;
+  g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
+  g.pad_mode = d->pad_mode;
+  g.vec = (d->C % 4 == 0) && (d->x_cstride % 4 == 0) && aligned16(x);
+  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
+  g.img_bs = (int64_t)d->H * d->W * d->x_cstride;
+  return g;
+}
+
+extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                                  const float* residual, float* y, int act, int batch_w, int64_t w_bstride,
+                                  void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !wf || !y || batch_w < 1 || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
+  if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  const int n_eff = batch_w > 1 ? 1 : d->N;
+  ConvGeom g = fwd_geom(d, x, n_eff);
+  ConvK la{x, g};
+  ConvWX lb{wf, g, w_bstride, d->K, (d->K % 4 == 0) && aligned16(wf) && (w_bstride % 4 == 0)};
+  ConvEp ep{y, bias, residual, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, act, g.dGW, g.dG,
+            (int64_t)d->OH * d->OW * d->y_cstride};
+  return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), batch_w, 1, (hipStream_t)stream);
+}
+
+extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
+                                    const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
+  if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;  // reflect: run on the padded extent, then fmi_reflect_pad_fold_f32
+  if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  const int n_eff = batch_w > 1 ? 1 : d->N;
+  const int s = d->stride;
+  for (int py = 0; py < s; ++py) {
+    for (int px = 0; px < s; ++px) {
+      const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
+      if (GH <= 0 || GW <= 0) continue;
+      ConvGeom g{};
+      g.N = n_eff; g.IH = d->OH; g.IW = d->OW; g.C = d->K; g.cstride = d->y_cstride;
+      g.GH = GH; g.GW = GW; g.S = 1;
+      g.kh0 = (py + d->pad) % s; g.kw0 = (px + d->pad) % s;
+      g.nty = g.kh0 < d->kh ? (d->kh - g.kh0 + s - 1) / s : 0;
+      g.ntx = g.kw0 < d->kw ? (d->kw - g.kw0 + s - 1) / s : 0;
+      g.dy0 = (py + d->pad - g.kh0) / s; g.dx0 = (px + d->pad - g.kw0) / s;
+      g.ystep = -1; g.xstep = -1; g.khstep = s; g.kwstep = s; g.kw = d->kw;
+      g.pad_mode = 0;
+      g.vec = (d->K % 4 == 0) && (d->y_cstride % 4 == 0) && aligned16(dy);
+      g.dGW = make_fastdiv(GW); g.dG = make_fastdiv(GH * GW); g.dC = make_fastdiv(g.C);
+      g.dntx = make_fastdiv(g.ntx > 0 ? g.ntx : 1);
+      g.img_bs = (int64_t)d->OH * d->OW * d->y_cstride;
+      if (g.nty == 0 || g.ntx == 0) { g.nty = 0; g.ntx = 1; }
+      ConvK la{dy, g};
+      ConvWX lb{wt, g, w_bstride, d->C, (d->C % 4 == 0) && aligned16(wt) && (w_bstride % 4 == 0)};
+      ConvEp ep{dx, bias, residual, GH, GW, s, py, px, d->H, d->W, d->x_cstride, 0, g.dGW, g.dG,
+                (int64_t)d->H * d->W * d->x_cstride};
+      rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), batch_w, 1, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  }
+  return FMI_OK;
+}
+
+extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, int batch_w,
+                                    int64_t w_bstride, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x || !dy || !dwf || batch_w < 1) return FMI_ERR_BAD_ARG;
+  if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  const int n_eff = batch_w > 1 ? 1 : d->N;
+  ConvGeom g = fwd_geom(d, x, n_eff);
+  const int Mg = g.Kdim(), Ng = d->K, Kg = g.Mdim();
+  WgradAX la{x, g};
+  DenseX lb{dy, (int64_t)d->y_cstride, (int64_t)d->OH * d->OW * d->y_cstride, Ng, Kg,
+            (d->K % 4 == 0) && (d->y_cstride % 4 == 0) && aligned16(dy)};
+  WgradEp ep{dwf, g, d->K, w_bstride};
+  // split the (long) pixel reduction over workgroups; partial sums meet through fp32 atomics
+  const int64_t tiles = ceil_div64(Mg, 128) * ceil_div64(Ng, Ng <= 32 ? 32 : (Ng <= 64 ? 64 : 128));
+  int64_t ksplit = 2048 / (tiles * batch_w);
+  const int64_t kmax = Kg / 512;
+  if (ksplit > kmax) ksplit = kmax;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit * batch_w > 65535) ksplit = 65535 / batch_w;
+  return launch_gemm(la, lb, ep, Mg, Ng, Kg, batch_w, (int)ksplit, (hipStream_t)stream);
+}
+
+#ifndef FMI_HOST_EMU
+// ---------------------------------------------------------------------------------------------
+// dbias[k] += sum_rows g[row*cstride + k]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ g, int64_t rows, int K, int cstride,
+                                                        float* __restrict__ dbias, int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int cg = 0; cg < K; cg += 64) {
+    const int c = cg + tx;
+    float s = 0.f;
+    if (c < K)
+      for (int64_t r = r0 + ty; r < r1; r += 4) s += g[r * cstride + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < K) atomicAdd(dbias + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    __syncthreads();
+  }
+}
+
+extern "C" int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream) {
+  if (!g || !dbias || rows <= 0 || K <= 0 || cstride < K) return FMI_ERR_BAD_ARG;
+  int64_t blocks = ceil_div64(rows, 256);
+  if (blocks > 2048) blocks = 2048;
+  const int64_t rpb = ceil_div64(rows, blocks);
+  blocks = ceil_div64(rows, rpb);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K, cstride,
+                     dbias, rpb);
+  return fmi_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gradient of nn.ReflectionPad2d(pad): gx[y][x] = sum of gpad over every padded position mirroring (y, x)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reflect_fold_kernel(const float* __restrict__ gp, float* __restrict__ gx, int N,
+                                                           int H, int W, int C, int pad, int64_t total) {
+  const int HP = H + 2 * pad, WP = W + 2 * pad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    // padded rows that map onto y: y+pad, and the mirrors pad-y (y in 1..pad), 2H-2-y+pad (y in H-1-pad..H-2)
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + pad;
+    if (y >= 1 && y <= pad) ys[ny++] = pad - y;
+    if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = 2 * H - 2 - y + pad;
+    xs[nx++] = x + pad;
+    if (x >= 1 && x <= pad) xs[nx++] = pad - x;
+    if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = 2 * W - 2 - x + pad;
+    float s = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) s += gp[(((int64_t)n * HP + ys[a]) * WP + xs[b]) * C + c];
+    gx[i] = s;
+  }
+}
+
+extern "C" int fmi_reflect_pad_fold_f32(const float* gpad, float* gx, int N, int H, int W, int C, int pad, void* stream) {
+  if (!gpad || !gx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || pad < 0 || pad >= H || pad >= W) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gpad, gx, N,
+                     H, W, C, pad, total);
+  return fmi_launch_status();
+}
+#endif  // FMI_HOST_EMU

@@ -1,0 +1,42 @@
+// Dense batched GEMM entry point (see include/fmi_hip.h: fmi_gemm_f32).
+#include "gemm_core.h"
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <class LA, class LB>
+static int run(const LA& la, const LB& lb, float* C, int M, int N, int K, int64_t sc_m, int64_t sc_n, int64_t sc_b,
+               int batch, float alpha, float beta, const float* bias, hipStream_t st) {
+  DenseEp ep{C, bias, sc_m, sc_n, sc_b, alpha, beta, 0};
+  return launch_gemm(la, lb, ep, M, N, K, batch, 1, st);
+}
+
+extern "C" int fmi_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sa_m, int64_t sa_k,
+                            int64_t sb_k, int64_t sb_n, int64_t sc_m, int64_t sc_n, int batch, int64_t sa_b,
+                            int64_t sb_b, int64_t sc_b, float alpha, float beta, const float* bias, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return FMI_ERR_BAD_ARG;
+  if (sa_m != 1 && sa_k != 1) return FMI_ERR_UNSUPPORTED;
+  if (sb_k != 1 && sb_n != 1) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool a_k = (sa_k == 1), b_k = (sb_k == 1);
+  // float4 loads need 16-byte aligned rows in every batch
+  const int64_t lda = a_k ? sa_m : sa_k, ldb = b_k ? sb_n : sb_k;
+  const int avec = aligned16(A) && (lda % 4 == 0) && (sa_b % 4 == 0);
+  const int bvec = aligned16(B) && (ldb % 4 == 0) && (sb_b % 4 == 0);
+  if (a_k && b_k) {
+    DenseK la{A, lda, sa_b, M, K, avec};
+    DenseK lb{B, ldb, sb_b, N, K, bvec};
+    return run(la, lb, C, M, N, K, sc_m, sc_n, sc_b, batch, alpha, beta, bias, st);
+  } else if (a_k && !b_k) {
+    DenseK la{A, lda, sa_b, M, K, avec};
+    DenseX lb{B, ldb, sb_b, N, K, bvec};
+    return run(la, lb, C, M, N, K, sc_m, sc_n, sc_b, batch, alpha, beta, bias, st);
+  } else if (!a_k && b_k) {
+    DenseX la{A, lda, sa_b, M, K, avec};
+    DenseK lb{B, ldb, sb_b, N, K, bvec};
+    return run(la, lb, C, M, N, K, sc_m, sc_n, sc_b, batch, alpha, beta, bias, st);
+  } else {
+    DenseX la{A, lda, sa_b, M, K, avec};
+    DenseX lb{B, ldb, sb_b, N, K, bvec};
+    return run(la, lb, C, M, N, K, sc_m, sc_n, sc_b, batch, alpha, beta, bias, st);
+  }
+}

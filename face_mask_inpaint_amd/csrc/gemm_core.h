@@ -1,0 +1,572 @@
+// fp32 matrix-core GEMM core for gfx950, shared by the dense batched GEMM, the implicit-GEMM
+// convolution family (forward / adjoint / weight-gradient) and the attention products.
+//
+// Machine mapping (MI355X_MICROARCH.md, cdna_hip_programming.md section 3 "FP32-input MFMA"):
+//  * v_mfma_f32_32x32x2_f32: one wave owns 32x32 output tiles, 16 accumulator registers each;
+//    A operand lane l = A[i = l&31][k = l>>5], B operand lane l = B[k = l>>5][j = l&31];
+//    D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  Exact f32 (fmaf chain).
+//  * 256-thread workgroups = 4 waves (one per SIMD), 2 workgroups per CU; operand tiles are staged
+//    k-major in LDS ([k][m] with a +4 float row pad) so every fragment read is a conflict-free
+//    ds_read_b32 of 32 consecutive floats per half-wave; global->register->LDS double buffering
+//    with ONE barrier per 16-deep k-step (register prefetch of tile t+1 is issued before the MFMAs
+//    of tile t and written to the other LDS buffer after them).
+//  * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
+#pragma once
+#include "common.h"
+
+#ifndef FMI_HOST_EMU
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+// ---- division by a runtime-invariant 32-bit divisor (Granlund-Montgomery round-up method) ----
+struct FastDiv {
+  uint32_t m, s1, s2, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 0 ? l - 1 : 0;
+  return f;
+}
+__host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t t = __umulhi(f.m, n);
+#else
+  const uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// ---- tile configurations ----
+template <int WM_, int WN_, int TM_, int TN_>
+struct TileCfg {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
+  static constexpr int LDA = BM + 4, LDB = BN + 4;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+};
+using Tile128x128 = TileCfg<2, 2, 2, 2>;
+using Tile128x64 = TileCfg<2, 2, 2, 1>;
+using Tile128x32 = TileCfg<4, 1, 1, 1>;
+using Tile64x64 = TileCfg<2, 2, 1, 1>;
+using Tile64x128 = TileCfg<2, 2, 1, 2>;
+using Tile32x128 = TileCfg<1, 4, 1, 1>;
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// =====================================================================================
+// Operand loaders.  KMODE: load4(slot, x, k) returns elements (x, k..k+3); otherwise
+// (x..x+3, k).  "x" is the row (A) / column (B) index, "k" the reduction index.  Out-of-range
+// elements read as zero.  prep(slot, x) lets a loader cache per-row state (x is fixed per slot).
+// =====================================================================================
+struct DenseK {  // reduction index contiguous in memory
+  static constexpr bool KMODE = true;
+  const float* p;
+  int64_t ld, bs;
+  int X, K, vec;
+  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
+  struct Ctx {};
+  __device__ Ctx prep(int) const { return Ctx{}; }
+  __device__ float4 load4(const Ctx&, int x, int k) const {
+    if (x >= X || k >= K) return zero4();
+    const float* q = p + (int64_t)x * ld + k;
+    if (vec && k + 3 < K) return ldg4(q);
+    float4 r = zero4();
+    r.x = q[0];
+    if (k + 1 < K) r.y = q[1];
+    if (k + 2 < K) r.z = q[2];
+    if (k + 3 < K) r.w = q[3];
+    return r;
+  }
+};
+
+struct DenseX {  // row/column index contiguous in memory
+  static constexpr bool KMODE = false;
+  const float* p;
+  int64_t ld, bs;
+  int X, K, vec;
+  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
+  struct Ctx {};
+  __device__ Ctx prep(int) const { return Ctx{}; }
+  __device__ float4 load4(const Ctx&, int x, int k) const {
+    if (x >= X || k >= K) return zero4();
+    const float* q = p + (int64_t)k * ld + x;
+    if (vec && x + 3 < X) return ldg4(q);
+    float4 r = zero4();
+    r.x = q[0];
+    if (x + 1 < X) r.y = q[1];
+    if (x + 2 < X) r.z = q[2];
+    if (x + 3 < X) r.w = q[3];
+    return r;
+  }
+};
+
+// Geometry of one implicit-GEMM launch.  Rows enumerate a grid [N][GH][GW] of "anchor" positions;
+// tap t = (i, j), i < nty, j < ntx, reads the image at (gy*S + dy0 + ystep*i, gx*S + dx0 + xstep*j)
+// and uses weight tap (kh0 + khstep*i)*kw + (kw0 + kwstep*j).
+//   forward conv : anchors = output pixels, S = stride, dy0 = -pad, steps = +1, all kh*kw taps
+//   adjoint, phase (py,px) of stride s: anchors = x pixels (gy*s+py, gx*s+px), image = dy, S = 1,
+//                  kh = kh0 + s*i with (py + pad - kh0) % s == 0, dy0 = (py+pad-kh0)/s, ystep = -1
+struct ConvGeom {
+  int N, IH, IW, C, cstride;  // gathered image (NHWC), C channels used, pixel pitch cstride
+  int GH, GW, S;
+  int nty, ntx, dy0, dx0, ystep, xstep, kh0, kw0, khstep, kwstep, kw;
+  int pad_mode, vec;
+  FastDiv dGW, dG, dC, dntx;
+  int64_t img_bs;  // batch (per-sample weight mode) stride of the image
+  __host__ __device__ int ntaps() const { return nty * ntx; }
+  __host__ __device__ int Kdim() const { return nty * ntx * C; }
+  __host__ __device__ int Mdim() const { return N * GH * GW; }
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x (tap, channel)
+  static constexpr bool KMODE = true;
+  const float* p;
+  ConvGeom g;
+  struct Ctx {  // cached anchor of one staged row
+    int ry, rx, rn;
+  };
+  __device__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
+  __device__ Ctx prep(int x) const {
+    Ctx c{0, 0, -1};
+    if (x >= g.Mdim()) return c;
+    const uint32_t n = fdiv((uint32_t)x, g.dG);
+    const uint32_t rem = (uint32_t)x - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    c.rn = (int)n;
+    c.ry = (int)gy * g.S + g.dy0;
+    c.rx = (int)gx * g.S + g.dx0;
+    return c;
+  }
+  __device__ __forceinline__ const float* pixel(const Ctx& c, int t, bool& ok) const {
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    int iy = c.ry + g.ystep * i, ix = c.rx + g.xstep * j;
+    if (g.pad_mode) {
+      iy = reflect_idx(iy, g.IH);
+      ix = reflect_idx(ix, g.IW);
+    }
+    ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
+    return p + ((int64_t)(c.rn * g.IH + iy) * g.IW + ix) * g.cstride;
+  }
+  __device__ float elem(const Ctx& c, int k) const {
+    const int t = (int)fdiv((uint32_t)k, g.dC);
+    if (t >= g.ntaps()) return 0.f;
+    bool ok;
+    const float* q = pixel(c, t, ok);
+    return ok ? q[k - t * g.C] : 0.f;
+  }
+  __device__ float4 load4(const Ctx& c, int, int k) const {
+    if (c.rn < 0) return zero4();
+    if (g.vec) {  // C % 4 == 0: the four k's share a tap
+      const int t = (int)fdiv((uint32_t)k, g.dC);
+      if (t >= g.ntaps()) return zero4();
+      bool ok;
+      const float* q = pixel(c, t, ok);
+      return ok ? ldg4(q + (k - t * g.C)) : zero4();
+    }
+    return make_float4(elem(c, k), elem(c, k + 1), elem(c, k + 2), elem(c, k + 3));
+  }
+};
+
+struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [tap][Cred][Nout]
+  static constexpr bool KMODE = false;
+  const float* p;
+  ConvGeom g;  // only the tap algebra and C are used
+  int64_t bs;
+  int Nout, vec;
+  struct Ctx {};
+  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
+  __device__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ const float* rowp(int k, bool& ok) const {
+    const int t = (int)fdiv((uint32_t)k, g.dC);
+    ok = t < g.ntaps();
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    return p + ((int64_t)wtap * g.C + (k - t * g.C)) * Nout;
+  }
+  __device__ float4 load4(const Ctx&, int x, int k) const {
+    bool ok;
+    const float* q = rowp(k, ok);
+    if (!ok || x >= Nout) return zero4();
+    q += x;
+    if (vec && x + 3 < Nout) return ldg4(q);
+    float4 r = zero4();
+    r.x = q[0];
+    if (x + 1 < Nout) r.y = q[1];
+    if (x + 2 < Nout) r.z = q[2];
+    if (x + 3 < Nout) r.w = q[3];
+    return r;
+  }
+};
+
+struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), reduction = anchors
+  static constexpr bool KMODE = false;
+  const float* p;
+  ConvGeom g;
+  struct Ctx {  // cached (tap, channel) of the first of the four rows a thread stages
+    int t0, c0;
+  };
+  __device__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
+  __device__ Ctx prep(int x) const {
+    Ctx c;
+    c.t0 = (int)fdiv((uint32_t)x, g.dC);
+    c.c0 = x - c.t0 * g.C;
+    return c;
+  }
+  __device__ __forceinline__ float elem_tc(int t, int c, int n, int gy, int gx) const {
+    if (t >= g.ntaps()) return 0.f;
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    int iy = gy * g.S + g.dy0 + g.ystep * i, ix = gx * g.S + g.dx0 + g.xstep * j;
+    if (g.pad_mode) {
+      iy = reflect_idx(iy, g.IH);
+      ix = reflect_idx(ix, g.IW);
+    }
+    if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return 0.f;
+    return p[((int64_t)(n * g.IH + iy) * g.IW + ix) * g.cstride + c];
+  }
+  __device__ float4 load4(const Ctx& cx, int x, int k) const {
+    const int t0 = cx.t0, c0 = cx.c0;
+    if (k >= g.Mdim()) return zero4();
+    const uint32_t n = fdiv((uint32_t)k, g.dG);
+    const uint32_t rem = (uint32_t)k - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    if (g.vec) {
+      if (t0 >= g.ntaps()) return zero4();
+      const int i = (int)fdiv((uint32_t)t0, g.dntx), j = t0 - i * g.ntx;
+      int iy = (int)gy * g.S + g.dy0 + g.ystep * i, ix = (int)gx * g.S + g.dx0 + g.xstep * j;
+      if (g.pad_mode) {
+        iy = reflect_idx(iy, g.IH);
+        ix = reflect_idx(ix, g.IW);
+      }
+      if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return zero4();
+      return ldg4(p + ((int64_t)((int)n * g.IH + iy) * g.IW + ix) * g.cstride + c0);
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int xe = x + e;
+      const int t = (int)fdiv((uint32_t)xe, g.dC);
+      v[e] = elem_tc(t, xe - t * g.C, (int)n, (int)gy, (int)gx);
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// =====================================================================================
+// Epilogues: row_off(row) -> element offset of the row, then store(off, col, acc).
+// =====================================================================================
+struct DenseEp {
+  float* c;
+  const float* bias;
+  int64_t sc_m, sc_n, bs;
+  float alpha, beta;
+  int atomic;
+  __device__ void set_batch(int b) { c += (int64_t)b * bs; }
+  __device__ int64_t row_off(int row) const { return (int64_t)row * sc_m; }
+  __device__ void store(int64_t off, int col, float v) const {
+    float* q = c + off + (int64_t)col * sc_n;
+    v *= alpha;
+    if (bias) v += bias[col];
+    if (atomic) {
+      atomicAdd(q, v);
+      return;
+    }
+    if (beta != 0.f) v += beta * *q;
+    *q = v;
+  }
+};
+
+struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py, gx*OS+px) of [N][OHt][OWt]
+  float* y;
+  const float* bias;
+  const float* res;
+  int GH, GW, OS, py, px, OHt, OWt, cstride, act;
+  FastDiv dGW, dG;
+  int64_t bs;
+  __device__ void set_batch(int b) {
+    y += (int64_t)b * bs;
+    if (res) res += (int64_t)b * bs;
+  }
+  __device__ int64_t row_off(int row) const {
+    const uint32_t n = fdiv((uint32_t)row, dG);
+    const uint32_t rem = (uint32_t)row - n * (uint32_t)(GH * GW);
+    const uint32_t gy = fdiv(rem, dGW);
+    const uint32_t gx = rem - gy * (uint32_t)GW;
+    return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
+  }
+  __device__ void store(int64_t off, int col, float v) const {
+    if (bias) v += bias[col];
+    if (res) v += res[off + col];
+    if (act == 1) v = tanhf(v);
+    else if (act == 2) v = fmaxf(v, 0.f);
+    y[off + col] = v;
+  }
+};
+
+struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 atomics across the split reduction
+  float* dw;
+  ConvGeom g;
+  int Kout;
+  int64_t bs;
+  __device__ void set_batch(int b) { dw += (int64_t)b * bs; }
+  __device__ int64_t row_off(int row) const {
+    const int t = (int)fdiv((uint32_t)row, g.dC);
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    return ((int64_t)wtap * g.C + (row - t * g.C)) * Kout;
+  }
+  __device__ void store(int64_t off, int col, float v) const { atomicAdd(dw + off + col, v); }
+};
+
+#ifndef FMI_HOST_EMU
+// =====================================================================================
+// The kernel.  grid.x = tiles_m*tiles_n (XCD-remapped), grid.y = batch*ksplit.
+// =====================================================================================
+template <class LA, class LB, class EP, class T>
+__global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
+                                                            int ksplit, int kchunk) {
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, LDA = T::LDA, LDB = T::LDB;
+  constexpr int NLA = BM / 64 > 0 ? BM / 64 : 1, NLB = BN / 64 > 0 ? BN / 64 : 1;  // float4 loads per thread per tile
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
+  float* As = lds;
+  float* Bs = lds + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int zb = blockIdx.y / ksplit, zs = blockIdx.y - zb * ksplit;
+  la.set_batch(zb);
+  lb.set_batch(zb);
+  ep.set_batch(zb);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = zs * kchunk;
+  int k_end = k_begin + kchunk;
+  if (k_end > K) k_end = K;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+
+  // per-thread staging coordinates
+  int ax[NLA], ak[NLA], bx[NLB], bk[NLB];
+  bool aact[NLA], bact[NLB];
+  typename LA::Ctx ca[NLA];
+  typename LB::Ctx cb[NLB];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    if (LA::KMODE) {
+      ax[j] = (tid >> 2) + 64 * j;
+      ak[j] = (tid & 3) * 4;
+      aact[j] = ax[j] < BM;
+    } else {
+      const int idx = tid + 256 * j;
+      ak[j] = idx / (BM / 4);
+      ax[j] = (idx % (BM / 4)) * 4;
+      aact[j] = ak[j] < BK;
+    }
+    ca[j] = la.prep(m0 + ax[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    if (LB::KMODE) {
+      bx[j] = (tid >> 2) + 64 * j;
+      bk[j] = (tid & 3) * 4;
+      bact[j] = bx[j] < BN;
+    } else {
+      const int idx = tid + 256 * j;
+      bk[j] = idx / (BN / 4);
+      bx[j] = (idx % (BN / 4)) * 4;
+      bact[j] = bk[j] < BK;
+    }
+    cb[j] = lb.prep(n0 + bx[j]);
+  }
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[NLA], rb[NLB];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) ra[j] = aact[j] ? la.load4(ca[j], m0 + ax[j], k0 + ak[j]) : zero4();
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) rb[j] = bact[j] ? lb.load4(cb[j], n0 + bx[j], k0 + bk[j]) : zero4();
+  };
+  auto lstore = [&](int buf) {
+    float* a = As + buf * BK * LDA;
+    float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      if (!aact[j]) continue;
+      if (LA::KMODE) {
+        a[(ak[j] + 0) * LDA + ax[j]] = ra[j].x;
+        a[(ak[j] + 1) * LDA + ax[j]] = ra[j].y;
+        a[(ak[j] + 2) * LDA + ax[j]] = ra[j].z;
+        a[(ak[j] + 3) * LDA + ax[j]] = ra[j].w;
+      } else {
+        *reinterpret_cast<float4*>(a + ak[j] * LDA + ax[j]) = ra[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      if (!bact[j]) continue;
+      if (LB::KMODE) {
+        b[(bk[j] + 0) * LDB + bx[j]] = rb[j].x;
+        b[(bk[j] + 1) * LDB + bx[j]] = rb[j].y;
+        b[(bk[j] + 2) * LDB + bx[j]] = rb[j].z;
+        b[(bk[j] + 3) * LDB + bx[j]] = rb[j].w;
+      } else {
+        *reinterpret_cast<float4*>(b + bk[j] * LDB + bx[j]) = rb[j];
+      }
+    }
+  };
+
+  if (k_begin < k_end) {
+    gload(k_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = k0 + BK < k_end;
+    if (more) gload(k0 + BK);
+    const float* a = As + buf * BK * LDA + wm + l31;
+    const float* b = Bs + buf * BK * LDB + wn + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float fa[T::TM], fb[T::TN];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) fa[i] = a[(kk + lh) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) fb[j] = b[(kk + lh) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31 of its 32x32 tile
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= M) continue;
+      const int64_t off = ep.row_off(row);
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        const int col = n0 + wn + j * 32 + l31;
+        if (col < N) ep.store(off, col, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// Host-side launcher: picks the tile from N (and M), validates the 32-bit index ranges the kernel assumes.
+template <class LA, class LB, class EP>
+static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, int K, int batch, int ksplit,
+                       hipStream_t st) {
+  if (M <= 0 || N <= 0 || K < 0 || batch <= 0 || ksplit <= 0) return FMI_ERR_BAD_ARG;
+  int kchunk = 16;
+  if (K == 0) {
+    ksplit = 1;  // empty reduction: the epilogue still writes bias / residual
+  } else {
+    kchunk = (int)ceil_div64(ceil_div64(K, ksplit), 16) * 16;
+    ksplit = (int)ceil_div64(K, kchunk);
+  }
+  const int64_t gy = (int64_t)batch * ksplit;
+  if (gy > 65535) return FMI_ERR_UNSUPPORTED;
+#define FMI_LAUNCH(TILE)                                                                                      \
+  do {                                                                                                        \
+    const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                 \
+    if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                   \
+    hipLaunchKernelGGL((gemm_mfma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
+                       0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                                  \
+  } while (0)
+  if (M <= 32 && N > 64) FMI_LAUNCH(Tile32x128);
+  else if (N <= 32) FMI_LAUNCH(Tile128x32);
+  else if (M <= 64 && N <= 64) FMI_LAUNCH(Tile64x64);
+  else if (M <= 64) FMI_LAUNCH(Tile64x128);
+  else if (N <= 64) FMI_LAUNCH(Tile128x64);
+  else FMI_LAUNCH(Tile128x128);
+#undef FMI_LAUNCH
+  return fmi_launch_status();
+}
+
+#else  // ------------------------------ FMI_HOST_EMU ------------------------------
+// Reference evaluation of the same (loader, loader, epilogue) triple with plain loops.
+template <class L>
+static void emu_dense(const L& l, int X, int K, float* out /*[X][K]*/) {
+  if (L::KMODE) {
+    for (int x = 0; x < X; ++x) {
+      auto c = l.prep(x);
+      for (int k = 0; k < ((K + 3) / 4) * 4; k += 4) {
+        float4 v = l.load4(c, x, k);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 4; ++i)
+          if (k + i < K) out[(int64_t)x * K + k + i] = e[i];
+      }
+    }
+  } else {
+    for (int x = 0; x < ((X + 3) / 4) * 4; x += 4) {
+      auto c = l.prep(x);
+      for (int k = 0; k < K; ++k) {
+        float4 v = l.load4(c, x, k);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        for (int i = 0; i < 4; ++i)
+          if (x + i < X) out[(int64_t)(x + i) * K + k] = e[i];
+      }
+    }
+  }
+}
+template <class LA, class LB, class EP>
+static int launch_gemm(const LA& la0, const LB& lb0, const EP& ep0, int M, int N, int K, int batch, int ksplit,
+                       hipStream_t) {
+  if (M <= 0 || N <= 0 || K < 0 || batch <= 0 || ksplit <= 0) return FMI_ERR_BAD_ARG;
+  float* A = new float[(int64_t)M * (K + 1)];
+  float* B = new float[(int64_t)N * (K + 1)];
+  for (int b = 0; b < batch; ++b) {
+    LA la = la0;
+    LB lb = lb0;
+    EP ep = ep0;
+    la.set_batch(b);
+    lb.set_batch(b);
+    ep.set_batch(b);
+    memset(A, 0, sizeof(float) * (int64_t)M * (K + 1));
+    memset(B, 0, sizeof(float) * (int64_t)N * (K + 1));
+    emu_dense(la, M, K, A);
+    emu_dense(lb, N, K, B);
+    for (int m = 0; m < M; ++m) {
+      const int64_t off = ep.row_off(m);
+      for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)A[(int64_t)m * K + k] * B[(int64_t)n * K + k];
+        ep.store(off, n, (float)acc);
+      }
+    }
+  }
+  delete[] A;
+  delete[] B;
+  return FMI_OK;
+}
+#endif

@@ -1,0 +1,264 @@
+/*
+ * fmi_hip.h -- C ABI of libfmi_hip.so: MI355X (gfx950) kernels for the
+ * reference-guided inpainting training hot path of syncdoth/face_mask_inpaint.
+ *
+ * Conventions
+ *  - every entry point is extern "C", takes raw DEVICE pointers + sizes, an
+ *    explicit hipStream_t (passed as void*), launches asynchronously and
+ *    returns an fmi_status (0 = ok).  Nothing is allocated or retained.
+ *  - activations are NHWC fp32 (channels contiguous) unless stated; "cstride"
+ *    arguments are the distance in floats between consecutive pixels so that
+ *    channel slices of a wider tensor can be read / written in place.
+ *  - unsupported arguments fail loudly (FMI_ERR_*); the reference's CUDA
+ *    upfirdn2d silently returns uninitialised memory for them
+ *    (modules/psp/stylegan2/op/upfirdn2d_kernel.cu:172-268).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *  - fmi_upfirdn2d_f32      <- upfirdn2d_op.upfirdn2d, op/upfirdn2d.cpp:12-23,
+ *                              kernel op/upfirdn2d_kernel.cu:52-272
+ *  - fmi_fused_bias_act_f32 <- fused.fused_bias_act, op/fused_bias_act.cpp:11-20,
+ *                              kernel op/fused_bias_act_kernel.cu:18-99
+ *  - everything else replaces stock ATen calls made by the nn.Modules on the
+ *    path (F.conv2d / conv_transpose2d / bmm / softmax / instance_norm /
+ *    interpolate / avg_pool / Adam ...); each prototype cites its call site.
+ */
+#ifndef FMI_HIP_H
+#define FMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  FMI_OK = 0,
+  FMI_ERR_BAD_ARG = 1,      /* null pointer, non-positive size, misaligned view */
+  FMI_ERR_UNSUPPORTED = 2,  /* shape / mode outside what the kernels implement */
+  FMI_ERR_LAUNCH = 3        /* hipGetLastError() != hipSuccess after the launch */
+} fmi_status;
+
+const char* fmi_status_string(int status);
+int fmi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Dense batched GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *   C[b] = alpha * A[b] . B[b] (+ bias[n]) + beta * C[b]
+ * A is M x K with element strides (sa_m, sa_k), one of which must be 1;
+ * B is K x N with (sb_k, sb_n), one of which must be 1; C has (sc_m, sc_n).
+ * Replaces torch.bmm / @ at example_guided_att.py:17,31, base_function.py:433,437,
+ * external_function.py:184,253 and F.linear at stylegan2/model.py:160-165.
+ * ---------------------------------------------------------------------- */
+int fmi_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
+                 int64_t sa_m, int64_t sa_k, int64_t sb_k, int64_t sb_n, int64_t sc_m, int64_t sc_n,
+                 int batch, int64_t sa_b, int64_t sb_b, int64_t sc_b,
+                 float alpha, float beta, const float* bias, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Convolution family as implicit GEMM (im2col gather -> LDS -> fp32 MFMA).
+ * All three entry points are described by the FORWARD convolution
+ *      y[N,OH,OW,K] = conv(x[N,H,W,C], w[K,C,kh,kw], stride, pad)
+ *      OH = (H + 2*pad - kh)/stride + 1
+ * A ConvTranspose2d (base_function.py:326-341) is the adjoint of that conv:
+ * its forward is fmi_conv2d_dgrad_f32, its input-gradient fmi_conv2d_fwd_f32
+ * and its weight-gradient fmi_conv2d_wgrad_f32 with x/dy exchanged.
+ * Weights are consumed in two packed layouts produced by fmi_weight_prepare:
+ *      wf[tap][C][K]   (tap = kh_i*kw + kw_i)  used by fwd, produced by wgrad
+ *      wt[tap][K][C]                            used by dgrad
+ * batch_w > 1 selects per-sample weights (ModulatedConv2d, stylegan2/model.py:
+ * 241-279): sample n uses w + n*w_bstride and N must equal batch_w.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int N, H, W, C;    /* x: conv input (the larger image for stride > 1) */
+  int OH, OW, K;     /* y: conv output */
+  int x_cstride;     /* floats between consecutive pixels of x (>= C) */
+  int y_cstride;     /* floats between consecutive pixels of y (>= K) */
+  int kh, kw, stride, pad;
+  int pad_mode;      /* 0 = zeros, 1 = reflect (nn.ReflectionPad2d, base_function.py:390) */
+} fmi_conv_desc;
+
+/* y = conv(x, wf) + bias[k] + residual ; bias/residual may be NULL.
+ * act: 0 none, 1 tanh, 2 relu, applied last. residual has y's layout. */
+int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                       const float* residual, float* y, int act, int batch_w, int64_t w_bstride, void* stream);
+/* dx = conv_adjoint(dy, wt) + bias[c] + residual (dx layout = x's).  With
+ * pad_mode = reflect the caller passes H,W of the PADDED input (see
+ * fmi_reflect_pad_fold_f32). */
+int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
+                         const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream);
+/* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf. */
+int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf,
+                         int batch_w, int64_t w_bstride, void* stream);
+/* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
+int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);
+/* fold the gradient w.r.t. a reflection-padded tensor [N,H+2p,W+2p,C] back onto [N,H,W,C]. */
+int fmi_reflect_pad_fold_f32(const float* gpad, float* gx, int N, int H, int W, int C, int pad, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Weight preparation, incl. SpectralNorm (external_function.py:30-41,70-72).
+ * One launch handles a whole network: entry i describes one conv weight in the
+ * torch layout w[rows][C*taps] (rows = K for Conv2d, = in_channels for
+ * ConvTranspose2d, which is also the conv-view K).
+ * If u != NULL: v <- normalize(W^T u); u <- normalize(W v); sigma = u.(W v);
+ * the packed copies hold W / sigma.  If u == NULL the packed copies hold W.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  const float* w;   /* [rows][C*taps] */
+  float* u;         /* [rows] or NULL */
+  float* v;         /* [C*taps] or NULL */
+  float* wf;        /* out [taps][C][rows] */
+  float* wt;        /* out [taps][rows][C] (may be NULL) */
+  float* sigma;     /* out [1] (may be NULL when u == NULL) */
+  int rows, C, taps, pad_;
+} fmi_weight_entry;
+int fmi_weight_prepare_f32(const fmi_weight_entry* entries_dev, int count, void* stream);
+
+typedef struct {
+  const float* w;      /* [rows][C*taps] */
+  const float* u;      /* live u (see DESIGN.md "u/v rebinding") or NULL */
+  const float* v;
+  const float* sigma;  /* sigma of the forward call this gradient belongs to */
+  const float* dwf;    /* [taps][C][rows] gradient w.r.t. the packed effective weight */
+  float* dw;           /* out [rows][C*taps], overwritten */
+  int rows, C, taps, pad_;
+} fmi_weight_grad_entry;
+int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries_dev, int count, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Row softmax over the last dimension (base_function.py:412,430,
+ * example_guided_att.py:30) and its backward, in place capable.
+ * ---------------------------------------------------------------------- */
+int fmi_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, void* stream);
+/* ds = p * (dp - sum_j p*dp) ; ds may alias dp */
+int fmi_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Bandwidth-class element-wise kernels (float4 vectorised).
+ * ---------------------------------------------------------------------- */
+enum {
+  FMI_EW_LRELU = 0,        /* y = x > 0 ? x : p0*x            (nn.LeakyReLU / ReLU with p0 = 0) */
+  FMI_EW_LRELU_BWD = 1,    /* y = a * (b > 0 ? 1 : p0)        a = grad, b = forward input */
+  FMI_EW_TANH_BWD = 2,     /* y = a * (1 - b*b)               b = forward output */
+  FMI_EW_ADD = 3,          /* y = a + b */
+  FMI_EW_SCALE = 4,        /* y = p0 * a */
+  FMI_EW_AXPY = 5,         /* y = p0 * a + b */
+  FMI_EW_MUL = 6,          /* y = a * b */
+  FMI_EW_RELU_BWD_OUT = 7, /* y = a * (b > 0)                 b = forward output */
+  FMI_EW_SOFTPLUS = 8,     /* y = log1p(exp(a)) (threshold 20, F.softplus) */
+  FMI_EW_SOFTPLUS_BWD = 9, /* y = a * sigmoid(b)              b = forward input */
+  FMI_EW_SUB = 10,         /* y = a - b */
+  FMI_EW_COUNT_
+};
+int fmi_eltwise_f32(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream);
+/* y = a * s[0] + b, s is a 1-element DEVICE tensor (Auto_Attn gamma, base_function.py:439) */
+int fmi_axpy_dev_f32(const float* a, const float* s, const float* b, float* y, int64_t n, void* stream);
+/* out[0] += scale * sum(a*b)  (caller zeroes out) */
+int fmi_dot_f32(const float* a, const float* b, int64_t n, float scale, float* out, void* stream);
+
+/* mask helpers (train_reference_fill.py:340, loss.py:88-95, example_guided_att.py:35) */
+int fmi_mask_binarise_i64(const int64_t* mask, float* out, int64_t n, void* stream);          /* (m > 0) ? 1 : 0, bit exact */
+/* y[p,c] = x[p,c] * (invert ? 1 - m[p] : m[p]) */
+int fmi_mask_mul_f32(const float* x, const float* m, float* y, int64_t pixels, int C, int invert, void* stream);
+/* out[p, 0:C] = (1-m[p]) * ref_att[p,:] + m[p] * ref[p,:]   (out pixel stride out_cstride) */
+int fmi_guide_blend_f32(const float* ref_att, const float* ref, const float* m, float* out,
+                        int64_t pixels, int C, int out_cstride, void* stream);
+/* backward: g has pixel stride g_cstride; d_ref_att = (1-m) g ; d_ref = m g */
+int fmi_guide_blend_bwd_f32(const float* g, const float* m, float* d_ref_att, float* d_ref,
+                            int64_t pixels, int C, int g_cstride, void* stream);
+/* z[p, 0:Z] = o_src[p,0:Z] + softplus(o_src[p,Z:2Z]) * eps_q ; z[p, Z:2Z] likewise from o_ref/eps_p
+ * (network.py:167-168,275-307 with the normal draws injected). */
+int fmi_vae_sample_f32(const float* o_src, const float* o_ref, const float* eps_q, const float* eps_p,
+                       float* z, int64_t pixels, int Z, void* stream);
+int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const float* o_ref, const float* eps_q,
+                           const float* eps_p, float* g_src, float* g_ref, int64_t pixels, int Z, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Pooling / resampling / normalisation (NHWC).
+ * ---------------------------------------------------------------------- */
+/* k x k mean pooling, stride k (nn.AvgPool2d(2,2) base_function.py:233; AdaptiveAvgPool2d 1024->256 model.py:79) */
+int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
+int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream);
+/* 2x2 max pooling (VGG16 features, loss.py:21-25); backward routes to the first maximum */
+int fmi_maxpool2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int fmi_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+/* bilinear, align_corners=True (model.py:10-12) with optional per-channel affine y = s*v + t
+ * (VGG input normalisation loss.py:51-52); in/out NHWC */
+int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
+                            const float* ch_scale, const float* ch_shift, void* stream);
+/* gx += ... (atomic scatter; caller zeroes gx) */
+int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW,
+                                const float* ch_scale, void* stream);
+/* InstanceNorm2d(affine) (base_function.py:47): stats[n][c] = {mean, rstd}; y = act((x-mean)*rstd*g + b),
+ * act = LeakyReLU(slope) fused when slope != 1. */
+int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2] zeroed*/, float* stats /*[N][C][2]*/,
+                           int N, int HW, int C, float eps, void* stream);
+int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
+                           int N, int HW, int C, float slope, void* stream);
+/* backward of y = lrelu(IN(x)): red[n][c] = {sum g', sum g'*xhat} (zeroed by caller), then gx; dgamma/dbeta += */
+int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                const float* beta, double* red, int N, int HW, int C, float slope, void* stream);
+int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                               const float* beta, const double* red, float* gx, float* dgamma, float* dbeta,
+                               int N, int HW, int C, float slope, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Reductions for the losses (loss.py:58-64,97-118; external_function.py:110-131,187-192).
+ * kind: 0 = sum |a-b| , 1 = sum (a-b)^2 , 2 = sum (a-c0)^2 (b ignored)
+ * out[0] += scale * reduction  (double-precision accumulation; caller zeroes out)
+ * ---------------------------------------------------------------------- */
+int fmi_reduce_loss_f32(int kind, const float* a, const float* b, int64_t n, float c0, float scale,
+                        float* out, void* stream);
+/* gradient of the above w.r.t. a: ga = gscale[0]*scale * d/da ; gscale is a DEVICE scalar (upstream grad) */
+int fmi_reduce_loss_bwd_f32(int kind, const float* a, const float* b, int64_t n, float c0, float scale,
+                            const float* gscale, float* ga, void* stream);
+/* gsym[b][i][j] = coef * (sgn(ga-gb)[i][j] + sgn(ga-gb)[j][i]) * gscale[0]  for the Gram/L1 style loss */
+int fmi_gram_l1_bwd_f32(const float* ga, const float* gb, float* gsym, int batch, int C, float coef,
+                        const float* gscale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Contextual loss (external_function.py:231-274), x,y NHWC features [N,P,C].
+ * ---------------------------------------------------------------------- */
+int fmi_cx_channel_mean_f32(const float* y, float* mu /*[C] zeroed*/, int64_t rows, int C, void* stream);
+/* out[p,:] = (x[p,:]-mu)/||x[p,:]-mu|| ; inv_norm[p] saved for backward */
+int fmi_cx_normalise_f32(const float* x, const float* mu, float* out, float* inv_norm, int64_t rows, int C, void* stream);
+int fmi_cx_normalise_bwd_f32(const float* g, const float* xn, const float* inv_norm, float* gx, int64_t rows, int C, void* stream);
+/* from cos[N][P][P] (row i = x point, col j = y point): per-row d_min, w = exp((1 - d/(dmin+1e-5))/h), row sums;
+ * cxij = w/rowsum written in place; colmax[n][j] + argmax over i; cx[n] = mean_j colmax; loss += -log(cx+1e-5)/N */
+int fmi_cx_rows_f32(float* cos_inout, float* dmin, int* argmin, float* rowsum, int N, int P, float h, void* stream);
+int fmi_cx_cols_f32(const float* cxij, float* colmax, int* colarg, int N, int P, void* stream);
+int fmi_cx_loss_f32(const float* colmax, float* cx /*[N]*/, float* loss /*[1] zeroed*/, int N, int P, float scale, void* stream);
+/* backward: writes dcos[N][P][P] (overwrites) */
+int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* argmin, const float* rowsum, const float* cos_unused,
+                   const int* colarg, const float* cx, const float* gscale, float* dcos, int N, int P, float h, float scale,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-tensor Adam (torch.optim.Adam defaults as used at train_reference_fill.py:309-315).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  float* p; const float* g; float* m; float* v; int64_t n;
+} fmi_adam_entry;
+int fmi_adam_step_f32(const fmi_adam_entry* entries_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The reference's own native ops (modules/psp/stylegan2/op).
+ * ---------------------------------------------------------------------- */
+/* in [major,in_h,in_w] (minor = 1, as op/upfirdn2d.py:96 always reshapes), kernel [kh,kw], out [major,out_h,out_w];
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1.  Generic up/down/kernel sizes are supported. */
+int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w,
+                      int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* x [.., C, step_b...] contiguous NCHW as in the reference: bias index = (i / step_b) % size_b.
+ * act: 1 linear, 3 leaky relu; grad: 0 forward, 1 first derivative w.r.t. x using ref = forward OUTPUT, 2 second (=0).
+ * bias / ref may be NULL. */
+int fmi_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* out, int64_t n,
+                           int step_b, int size_b, int act, int grad, float alpha, float scale, void* stream);
+/* NHWC variant used by the product's StyledConv: y = lrelu(x + bias[c] + nw[0]*noise[p]) * scale */
+int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise, const float* nw, float* y,
+                           int64_t pixels, int C, float alpha, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMI_HIP_H */
