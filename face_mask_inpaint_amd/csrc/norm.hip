@@ -1,0 +1,206 @@
+// InstanceNorm2d(affine=True) on NHWC fp32, fused with the LeakyReLU that always follows it on the
+// hot path (base_function.py:348-356).  Bandwidth kernels.  Statistics are accumulated per thread in
+// fp32 over a short pixel run, then in fp64 across threads / workgroups (fp64 atomics), so the
+// E[x^2]-E[x]^2 form does not lose precision at 512x512 planes.
+//
+// Layout of a workgroup: 256 threads = PL pixel lanes x CG channel groups (4 channels each), CG = C/4.
+#include "common.h"
+
+#define ROWS_PER_BLOCK 512  // pixels per workgroup chunk
+
+// sums[n][c][0..1] += (sum f0, sum f1) where (f0,f1) = fn(x, g) per element
+template <int MODE>  // 0: (x, x*x)   1: backward reductions (g', g'*xhat)
+__global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, double* __restrict__ sums, int HW,
+                                                        int C, float slope) {
+  __shared__ float red[256 * 8];
+  const int CG = C >> 2, PL = 256 / CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  const int n = blockIdx.y;
+  const int p0 = blockIdx.x * ROWS_PER_BLOCK;
+  int p1 = p0 + ROWS_PER_BLOCK;
+  if (p1 > HW) p1 = HW;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  float mean[4] = {0, 0, 0, 0}, rstd[4] = {1, 1, 1, 1}, gm[4] = {1, 1, 1, 1}, bt[4] = {0, 0, 0, 0};
+  if (MODE == 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = cg * 4 + e;
+      mean[e] = stats[((int64_t)n * C + c) * 2];
+      rstd[e] = stats[((int64_t)n * C + c) * 2 + 1];
+      gm[e] = gamma[c];
+      bt[e] = beta[c];
+    }
+  }
+  if (pl < PL) {
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const int64_t o = ((int64_t)n * HW + p) * C + cg * 4;
+      const float4 v = *reinterpret_cast<const float4*>(x + o);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0[e] += xv[e];
+          a1[e] += xv[e] * xv[e];
+        }
+      } else {
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + o);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mean[e]) * rstd[e];
+          const float pre = xh * gm[e] + bt[e];
+          const float gp = pre > 0.f ? gv[e] : gv[e] * slope;
+          a0[e] += gp;
+          a1[e] += gp * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[threadIdx.x * 8 + e] = a0[e];
+    red[threadIdx.x * 8 + 4 + e] = a1[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < CG) {  // thread cg sums over the pixel lanes in fp64
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int l = 0; l < PL; ++l) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0[e] += red[(l * CG + threadIdx.x) * 8 + e];
+        s1[e] += red[(l * CG + threadIdx.x) * 8 + 4 + e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double* d = sums + ((int64_t)n * C + threadIdx.x * 4 + e) * 2;
+      atomicAdd(d, s0[e]);
+      atomicAdd(d + 1, s1[e]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) in_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, int NC,
+                                                          int HW, float eps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NC) return;
+  const double m = sums[2 * i] / HW;
+  double var = sums[2 * i + 1] / HW - m * m;
+  if (var < 0) var = 0;
+  stats[2 * i] = (float)m;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+static int check_c(int C) {
+  const int cg = C / 4;
+  if (C % 4 != 0 || cg < 1 || cg > 256 || (cg & (cg - 1)) != 0) return FMI_ERR_UNSUPPORTED;  // CG must divide 256
+  return FMI_OK;
+}
+
+extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats, int N, int HW, int C, float eps, void* stream) {
+  if (!x || !sums || !stats || N <= 0 || HW <= 0 || C <= 0 || ((uintptr_t)x & 15)) return FMI_ERR_BAD_ARG;
+  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((HW + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, N);
+  hipLaunchKernelGGL((in_reduce_kernel<0>), grid, dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, sums, HW, C, 1.f);
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const double*)sums, stats, N * C, HW, eps);
+  return fmi_launch_status();
+}
+
+__global__ void __launch_bounds__(256) in_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int HW, int C4, int64_t total4, float slope) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    const int n = (int)(i / ((int64_t)HW * C4));
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float xv[4] = {v.x, v.y, v.z, v.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = cg * 4 + e;
+      const float* s = stats + ((int64_t)n * C4 * 4 + c) * 2;
+      const float pre = (xv[e] - s[0]) * s[1] * gamma[c] + beta[c];
+      o[e] = pre > 0.f ? pre : pre * slope;
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+extern "C" int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
+                                      int N, int HW, int C, float slope, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return FMI_ERR_BAD_ARG;
+  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)N * HW * (C / 4);
+  hipLaunchKernelGGL(in_apply_kernel, dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y,
+                     HW, C / 4, total4, slope);
+  return fmi_launch_status();
+}
+
+extern "C" int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                           const float* beta, double* red, int N, int HW, int C, float slope, void* stream) {
+  if (!x || !gy || !stats || !gamma || !beta || !red || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)gy & 15))
+    return FMI_ERR_BAD_ARG;
+  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
+  dim3 grid((HW + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, N);
+  hipLaunchKernelGGL((in_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, stats, gamma, beta, red, HW, C, slope);
+  return fmi_launch_status();
+}
+
+// gx = rstd*gamma*(g' - mean(g') - xhat*mean(g'*xhat))
+__global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const double* __restrict__ red,
+                                                           float* __restrict__ gx, int HW, int C4, int64_t total4,
+                                                           float slope) {
+  const float inv_hw = 1.f / (float)HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % C4);
+    const int n = (int)(i / ((int64_t)HW * C4));
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+    const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = cg * 4 + e;
+      const int64_t sc = (int64_t)n * C4 * 4 + c;
+      const float mean = stats[sc * 2], rstd = stats[sc * 2 + 1];
+      const float xh = (xv[e] - mean) * rstd;
+      const float pre = xh * gamma[c] + beta[c];
+      const float gp = pre > 0.f ? gv[e] : gv[e] * slope;
+      const float m1 = (float)red[sc * 2] * inv_hw, m2 = (float)red[sc * 2 + 1] * inv_hw;
+      o[e] = rstd * gamma[c] * (gp - m1 - xh * m2);
+    }
+    reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+__global__ void __launch_bounds__(256) in_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int N, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int n = 0; n < N; ++n) {
+    s1 += red[((int64_t)n * C + c) * 2];
+    s2 += red[((int64_t)n * C + c) * 2 + 1];
+  }
+  dbeta[c] += (float)s1;
+  dgamma[c] += (float)s2;
+}
+extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                          const float* beta, const double* red, float* gx, float* dgamma, float* dbeta, int N,
+                                          int HW, int C, float slope, void* stream) {
+  if (!x || !gy || !stats || !gamma || !beta || !red || !gx || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) ||
+      ((uintptr_t)gy & 15) || ((uintptr_t)gx & 15))
+    return FMI_ERR_BAD_ARG;
+  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total4 = (int64_t)N * HW * (C / 4);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, st, x, gy, stats, gamma, beta, red, gx, HW,
+                     C / 4, total4, slope);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(in_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, dgamma, dbeta, N, C);
+  return fmi_launch_status();
+}

@@ -1,0 +1,218 @@
+// Pooling and bilinear resampling on NHWC fp32 tensors.  Bandwidth kernels: one thread per group of four
+// channels (float4) of an output pixel when C % 4 == 0, otherwise one thread per element.
+#include "common.h"
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int V>
+struct VecT;
+template <>
+struct VecT<1> {
+  typedef float T;
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ void add(float& a, float b) { a += b; }
+  static __device__ __forceinline__ void scale(float& a, float s) { a *= s; }
+};
+template <>
+struct VecT<4> {
+  typedef float4 T;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ void add(float4& a, float4 b) {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  static __device__ __forceinline__ void scale(float4& a, float s) {
+    a.x *= s; a.y *= s; a.z *= s; a.w *= s;
+  }
+};
+
+// ---- k x k average pooling -------------------------------------------------------------------
+template <int V>
+__global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                      int CV, int k, int64_t total) {
+  typedef typename VecT<V>::T T;
+  const int OH = H / k, OW = W / k;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % CV);
+    int64_t r = i / CV;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    T s = VecT<V>::zero();
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b)
+        VecT<V>::add(s, reinterpret_cast<const T*>(x)[(((int64_t)n * H + oy * k + a) * W + ox * k + b) * CV + c]);
+    VecT<V>::scale(s, inv);
+    reinterpret_cast<T*>(y)[i] = s;
+  }
+}
+template <int V>
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int H,
+                                                          int W, int CV, int k, int64_t total) {
+  typedef typename VecT<V>::T T;
+  const int OH = H / k, OW = W / k;
+  const float inv = 1.f / (float)(k * k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % CV);
+    int64_t r = i / CV;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    T v = VecT<V>::zero();
+    if (yy / k < OH && xx / k < OW) {
+      v = reinterpret_cast<const T*>(gy)[(((int64_t)n * OH + yy / k) * OW + xx / k) * CV + c];
+      VecT<V>::scale(v, inv);
+    }
+    reinterpret_cast<T*>(gx)[i] = v;
+  }
+}
+
+extern "C" int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H / k <= 0 || W / k <= 0) return FMI_ERR_BAD_ARG;
+  const bool v4 = (C % 4 == 0) && al16(x) && al16(y);
+  const int CV = v4 ? C / 4 : C;
+  const int64_t total = (int64_t)N * (H / k) * (W / k) * CV;
+  if (v4) hipLaunchKernelGGL((avgpool_kernel<4>), dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, CV, k, total);
+  else hipLaunchKernelGGL((avgpool_kernel<1>), dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, CV, k, total);
+  return fmi_launch_status();
+}
+extern "C" int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream) {
+  if (!gy || !gx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H / k <= 0 || W / k <= 0) return FMI_ERR_BAD_ARG;
+  const bool v4 = (C % 4 == 0) && al16(gx) && al16(gy);
+  const int CV = v4 ? C / 4 : C;
+  const int64_t total = (int64_t)N * H * W * CV;
+  if (v4) hipLaunchKernelGGL((avgpool_bwd_kernel<4>), dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, CV, k, total);
+  else hipLaunchKernelGGL((avgpool_bwd_kernel<1>), dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, CV, k, total);
+  return fmi_launch_status();
+}
+
+// ---- 2 x 2 max pooling (floor mode); the gradient goes to the FIRST maximum in row-major window order ----
+__global__ void __launch_bounds__(256) maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                       int C, int64_t total) {
+  const int OH = H / 2, OW = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const float* p = x + (((int64_t)n * H + oy * 2) * W + ox * 2) * C + c;
+    float m = p[0];
+    m = fmaxf(m, p[C]);
+    m = fmaxf(m, p[(int64_t)W * C]);
+    m = fmaxf(m, p[(int64_t)W * C + C]);
+    y[i] = m;
+  }
+}
+__global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, int H, int W, int C, int64_t total) {
+  const int OH = H / 2, OW = W / 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    const int oy = yy >> 1, ox = xx >> 1;
+    float g = 0.f;
+    if (oy < OH && ox < OW) {
+      const float* p = x + (((int64_t)n * H + oy * 2) * W + ox * 2) * C + c;
+      const float v0 = p[0], v1 = p[C], v2 = p[(int64_t)W * C], v3 = p[(int64_t)W * C + C];
+      int arg = 0;
+      float m = v0;
+      if (v1 > m) { m = v1; arg = 1; }
+      if (v2 > m) { m = v2; arg = 2; }
+      if (v3 > m) { m = v3; arg = 3; }
+      if (arg == ((yy & 1) * 2 + (xx & 1))) g = gy[(((int64_t)n * OH + oy) * OW + ox) * C + c];
+    }
+    gx[i] = g;
+  }
+}
+extern "C" int fmi_maxpool2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  if (!x || !y || N <= 0 || H < 2 || W < 2 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, total);
+  return fmi_launch_status();
+}
+extern "C" int fmi_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
+  if (!x || !gy || !gx || N <= 0 || H < 2 || W < 2 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, gy, gx, H, W, C, total);
+  return fmi_launch_status();
+}
+
+// ---- bilinear, align_corners=True (same source-index arithmetic as ATen's upsample_bilinear2d) ----
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_of(int o, int in, int out) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float r = scale * (float)o;
+  Lerp l;
+  l.i0 = (int)r;
+  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+  l.l1 = r - (float)l.i0;
+  l.l0 = 1.f - l.l1;
+  return l;
+}
+__global__ void __launch_bounds__(256) resize_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                     int OH, int OW, const float* __restrict__ mean,
+                                                     const float* __restrict__ stdv, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const Lerp ly = lerp_of(oy, H, OH), lx = lerp_of(ox, W, OW);
+    const float* b = x + (int64_t)n * H * W * C + c;
+    const float v00 = b[((int64_t)ly.i0 * W + lx.i0) * C], v01 = b[((int64_t)ly.i0 * W + lx.i1) * C];
+    const float v10 = b[((int64_t)ly.i1 * W + lx.i0) * C], v11 = b[((int64_t)ly.i1 * W + lx.i1) * C];
+    float v = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    if (mean) v = (v - mean[c]) / stdv[c];
+    y[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) resize_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int H, int W,
+                                                         int C, int OH, int OW, const float* __restrict__ stdv,
+                                                         int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const Lerp ly = lerp_of(oy, H, OH), lx = lerp_of(ox, W, OW);
+    float g = gy[i];
+    if (stdv) g = g / stdv[c];
+    float* b = gx + (int64_t)n * H * W * C + c;
+    atomicAdd(b + ((int64_t)ly.i0 * W + lx.i0) * C, ly.l0 * lx.l0 * g);
+    atomicAdd(b + ((int64_t)ly.i0 * W + lx.i1) * C, ly.l0 * lx.l1 * g);
+    atomicAdd(b + ((int64_t)ly.i1 * W + lx.i0) * C, ly.l1 * lx.l0 * g);
+    atomicAdd(b + ((int64_t)ly.i1 * W + lx.i1) * C, ly.l1 * lx.l1 * g);
+  }
+}
+extern "C" int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
+                                       const float* ch_mean, const float* ch_std, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  if ((ch_mean == nullptr) != (ch_std == nullptr)) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * OH * OW * C;
+  hipLaunchKernelGGL(resize_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, OH, OW,
+                     ch_mean, ch_std, total);
+  return fmi_launch_status();
+}
+extern "C" int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW,
+                                           const float* ch_std, void* stream) {
+  if (!gy || !gx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * OH * OW * C;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, C, OH,
+                     OW, ch_std, total);
+  return fmi_launch_status();
+}

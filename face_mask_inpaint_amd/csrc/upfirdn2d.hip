@@ -1,0 +1,106 @@
+// upfirdn2d: zero-insert up-sampling, padding / cropping, FIR filtering with the flipped kernel and
+// down-sampling of [major][H][W] planes, i.e. the native op of modules/psp/stylegan2/op.
+//
+// MI355X mapping (HBM-bound: every input and output element should cross HBM once):
+//  * one 256-thread workgroup produces a TH x TW = 16 x 64 output tile of one plane; lanes run along x so
+//    that global loads and stores are contiguous 256-byte rows per wave;
+//  * the input footprint of the tile (with zero fill outside the image) and the flipped FIR taps are staged
+//    in LDS once, the up-sampling zeros are never materialised: each output only visits the taps whose
+//    up-sampled coordinate lands on a real sample (poly-phase form);
+//  * any up / down / kernel size is accepted (the reference's CUDA kernel returns uninitialised memory
+//    outside six hard-coded modes, op/upfirdn2d_kernel.cu:172-268).
+#include "common.h"
+
+#define UF_TH 16
+#define UF_TW 64
+
+__device__ __forceinline__ int floordiv(int a, int b) {
+  int q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}
+
+struct UfParams {
+  int major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+  int tile_in_h, tile_in_w, tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ in, const float* __restrict__ kernel,
+                                                        float* __restrict__ out, UfParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sk = smem;                 // [kh][kw] flipped taps
+  float* sx = smem + p.kh * p.kw;   // [tile_in_h][tile_in_w]
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % p.tiles_x;
+  b /= p.tiles_x;
+  const int ty = b % p.tiles_y;
+  const int plane = b / p.tiles_y;
+  const int oy0 = ty * UF_TH, ox0 = tx * UF_TW;
+  // first up-sampled coordinate touched by the tile and the input sample at / before it
+  const int iy0 = floordiv(oy0 * p.down_y - p.pad_y0, p.up_y);
+  const int ix0 = floordiv(ox0 * p.down_x - p.pad_x0, p.up_x);
+  for (int t = tid; t < p.kh * p.kw; t += 256) {
+    const int ky = t / p.kw, kx = t - ky * p.kw;
+    sk[t] = kernel[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+  }
+  const float* ip = in + (int64_t)plane * p.in_h * p.in_w;
+  for (int t = tid; t < p.tile_in_h * p.tile_in_w; t += 256) {
+    const int ry = t / p.tile_in_w, rx = t - ry * p.tile_in_w;
+    const int iy = iy0 + ry, ix = ix0 + rx;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) v = ip[(int64_t)iy * p.in_w + ix];
+    sx[t] = v;
+  }
+  __syncthreads();
+  float* op = out + (int64_t)plane * p.out_h * p.out_w;
+  const int lx = tid & (UF_TW - 1);
+  const int ox = ox0 + lx;
+  if (ox >= p.out_w) return;
+  const int ux0 = ox * p.down_x - p.pad_x0;             // up-sampled x of tap kx = 0
+  int kx_first = (-ux0) % p.up_x;                       // first kx with (ux0 + kx) % up_x == 0
+  if (kx_first < 0) kx_first += p.up_x;
+  for (int ly = tid / UF_TW; ly < UF_TH; ly += 256 / UF_TW) {
+    const int oy = oy0 + ly;
+    if (oy >= p.out_h) break;
+    const int uy0 = oy * p.down_y - p.pad_y0;
+    int ky_first = (-uy0) % p.up_y;
+    if (ky_first < 0) ky_first += p.up_y;
+    float acc = 0.f;
+    for (int ky = ky_first; ky < p.kh; ky += p.up_y) {
+      const int ry = (uy0 + ky) / p.up_y - iy0;  // exact division; may be negative only outside the staged tile -> guarded
+      if ((unsigned)ry >= (unsigned)p.tile_in_h) continue;
+      for (int kx = kx_first; kx < p.kw; kx += p.up_x) {
+        const int rx = (ux0 + kx) / p.up_x - ix0;
+        if ((unsigned)rx >= (unsigned)p.tile_in_w) continue;
+        acc += sx[ry * p.tile_in_w + rx] * sk[ky * p.kw + kx];
+      }
+    }
+    op[(int64_t)oy * p.out_w + ox] = acc;
+  }
+}
+
+extern "C" int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w, int kh,
+                                 int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                 int pad_y1, void* stream) {
+  if (!in || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0) return FMI_ERR_BAD_ARG;
+  if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return FMI_ERR_BAD_ARG;
+  UfParams p;
+  p.major = major; p.in_h = in_h; p.in_w = in_w; p.kh = kh; p.kw = kw;
+  p.up_x = up_x; p.up_y = up_y; p.down_x = down_x; p.down_y = down_y; p.pad_x0 = pad_x0; p.pad_y0 = pad_y0;
+  const int full_h = in_h * up_y + pad_y0 + pad_y1 - kh, full_w = in_w * up_x + pad_x0 + pad_x1 - kw;
+  if (full_h < 0 || full_w < 0) return FMI_ERR_BAD_ARG;
+  p.out_h = full_h / down_y + 1;
+  p.out_w = full_w / down_x + 1;
+  // input rows touched by a tile: up-sampled extent (TH-1)*down + kh, i.e. at most that / up + 2 samples
+  p.tile_in_h = ((UF_TH - 1) * down_y + kh - 1) / up_y + 2;
+  p.tile_in_w = ((UF_TW - 1) * down_x + kw - 1) / up_x + 2;
+  const size_t lds = sizeof(float) * ((size_t)kh * kw + (size_t)p.tile_in_h * p.tile_in_w);
+  if (lds > 64 * 1024) return FMI_ERR_UNSUPPORTED;
+  p.tiles_x = (p.out_w + UF_TW - 1) / UF_TW;
+  p.tiles_y = (p.out_h + UF_TH - 1) / UF_TH;
+  const int64_t blocks = (int64_t)major * p.tiles_x * p.tiles_y;
+  if (blocks > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, in, kernel, out, p);
+  return fmi_launch_status();
+}

@@ -1,0 +1,770 @@
+"""Autograd glue between torch tensors and the HIP kernels of libfmi_hip.so.
+
+Everything here works on *NHWC* fp32 device tensors (shape ``[N, H, W, C]``, contiguous).  torch is used for
+device memory, the caching allocator, streams and the autograd tape only -- every floating-point operation of
+the hot path is a call into the C ABI (``include/fmi_hip.h``).  There is no CPU path: a missing library or a
+CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, FmiError
+
+EW_LRELU, EW_LRELU_BWD, EW_TANH_BWD, EW_ADD, EW_SCALE, EW_AXPY, EW_MUL, EW_RELU_BWD_OUT, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_SUB = range(11)
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
+# scratch budget for one attention score chunk (kept well inside the 256 MB Infinity Cache)
+ATTN_CHUNK_BYTES = 96 * 1024 * 1024
+
+
+def _L():
+    return _lib.lib()
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor], off: int = 0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise FmiError("face_mask_inpaint_amd ops need device tensors (there is no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise FmiError(f"expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise FmiError("expected a contiguous tensor")
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """NCHW-shaped tensor -> NHWC contiguous (free when x is already channels-last in memory)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    """NHWC contiguous -> NCHW-shaped view (channels_last strides, no copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw wrappers (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def gemm_raw(a_ptr, b_ptr, c_ptr, M, N, K, sa, sb, sc, batch=1, bs=(0, 0, 0), alpha=1.0, beta=0.0, bias=None):
+    _L().gemm_f32(a_ptr, b_ptr, c_ptr, M, N, K, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], batch, bs[0], bs[1], bs[2],
+                  alpha, beta, _p(bias), _st())
+
+
+def eltwise(op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, p0: float = 0.0, out: Optional[torch.Tensor] = None):
+    _chk(a, b)
+    y = torch.empty_like(a) if out is None else out
+    if a.numel():
+        _L().eltwise_f32(op, _p(a), _p(b), _p(y), a.numel(), float(p0), _st())
+    return y
+
+
+def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None) -> Tuple[ConvDesc, int, int]:
+    oh = (h + 2 * pad - kh) // stride + 1
+    ow = (w + 2 * pad - kw) // stride + 1
+    return ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode), oh, ow
+
+
+# ---------------------------------------------------------------------------------------------------
+# weight preparation (spectral norm + packing) for a whole network in one launch
+# ---------------------------------------------------------------------------------------------------
+class PackedWeight:
+    """Per-call packed effective weight of one conv: wf [taps][C][K] (autograd tensor), wt [taps][K][C]."""
+
+    __slots__ = ("wf", "wt", "rows", "C", "kh", "kw")
+
+    def __init__(self, wf, wt, rows, Cc, kh, kw):
+        self.wf, self.wt, self.rows, self.C, self.kh, self.kw = wf, wt, rows, Cc, kh, kw
+
+
+class _WeightPrepare(torch.autograd.Function):
+    """outputs: sigma[n], wf_0..wf_{n-1} (differentiable), wt_0..wt_{n-1} (twins for the adjoint kernels)."""
+
+    @staticmethod
+    def forward(ctx, metas, *ws):
+        # metas[i] = (u, v) parameters or (None, None); ws[i] = weight in torch layout [rows][C][kh][kw]
+        lib = _L()
+        n = len(ws)
+        dev = ws[0].device
+        sig = torch.ones(n, device=dev, dtype=torch.float32)
+        entries = (_lib.WeightEntry * n)()
+        wfs, wts = [], []
+        for i, (w, (u, v)) in enumerate(zip(ws, metas)):
+            _chk(w, u, v)
+            rows, cc, kh, kw = w.shape
+            if u is not None and (rows > 1024 or cc * kh * kw > 8192):
+                raise FmiError("spectral-norm weight too large for the single-workgroup kernel")
+            wf = torch.empty((kh * kw, cc, rows), device=dev, dtype=torch.float32)
+            wt = torch.empty((kh * kw, rows, cc), device=dev, dtype=torch.float32)
+            e = entries[i]
+            e.w = w.data_ptr()
+            e.u = u.data_ptr() if u is not None else None
+            e.v = v.data_ptr() if v is not None else None
+            e.wf, e.wt = wf.data_ptr(), wt.data_ptr()
+            e.sigma = sig.data_ptr() + 4 * i
+            e.rows, e.C, e.taps = rows, cc, kh * kw
+            wfs.append(wf)
+            wts.append(wt)
+        lib.weight_prepare_f32(entries, n, _st())
+        ctx.metas, ctx.ws, ctx.sig = metas, ws, sig
+        ctx.mark_non_differentiable(sig, *wts)
+        return (sig,) + tuple(wfs) + tuple(wts)
+
+    @staticmethod
+    def backward(ctx, _gsig, *gs):
+        lib = _L()
+        n = len(ctx.ws)
+        gwf = gs[:n]
+        live = [i for i, g in enumerate(gwf) if g is not None and ctx.needs_input_grad[1 + i]]
+        grads: List[Optional[torch.Tensor]] = [None] * n
+        if live:
+            entries = (_lib.WeightGradEntry * len(live))()
+            keep = []
+            for j, i in enumerate(live):
+                w = ctx.ws[i]
+                u, v = ctx.metas[i]
+                g = gwf[i].contiguous()
+                dw = torch.empty_like(w)
+                keep.append(g)
+                e = entries[j]
+                e.w = w.data_ptr()
+                # u / v are read LIVE (not snapshotted): this reproduces the reference's `.data` rebinding,
+                # see DESIGN.md "SpectralNorm state" and oracle/picnet_cpu.py:sn_weight
+                e.u = u.data_ptr() if u is not None else None
+                e.v = v.data_ptr() if v is not None else None
+                e.sigma = ctx.sig.data_ptr() + 4 * i
+                e.dwf = g.data_ptr()
+                e.dw = dw.data_ptr()
+                e.rows, e.C, e.taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                grads[i] = dw
+            lib.weight_grad_f32(entries, len(live), _st())
+        return (None,) + tuple(grads)
+
+
+def prepare_weights(items: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]]) -> List[PackedWeight]:
+    """items: (weight[rows,C,kh,kw], u or None, v or None).  One launch; returns PackedWeight per item."""
+    metas = tuple((u, v) for _, u, v in items)
+    ws = tuple(w for w, _, _ in items)
+    n = len(ws)
+    res = _WeightPrepare.apply(metas, *ws)
+    return [PackedWeight(res[1 + i], res[1 + n + i], w.shape[0], w.shape[1], w.shape[2], w.shape[3]) for i, w in enumerate(ws)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolution family
+# ---------------------------------------------------------------------------------------------------
+def _act_bwd(g, y, act):
+    if act == ACT_TANH:
+        return eltwise(EW_TANH_BWD, g, y)
+    if act == ACT_RELU:
+        return eltwise(EW_RELU_BWD_OUT, g, y)
+    return g
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(x, W) + bias + residual); x [N,H,W,C], wf [taps][C][K]."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act):
+        _chk(x, wf, bias, residual)
+        lib = _L()
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+        lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
+        ctx.save_for_backward(x, wf, y if act else None)
+        ctx.wt, ctx.cfg, ctx.has = wt, (kh, kw, stride, pad, pad_mode, act), (bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _L()
+        x, wf, y = ctx.saved_tensors
+        kh, kw, stride, pad, pad_mode, act = ctx.cfg
+        gy = gy.contiguous()
+        if act:
+            gy = _act_bwd(gy, y, act)
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        gx = gwf = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            if pad_mode == 1:  # adjoint w.r.t. the reflection-padded tensor, then fold (base_function.py:390)
+                hp, wp = h + 2 * pad, w + 2 * pad
+                d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0)
+                gpad = torch.empty((n, hp, wp, c), device=x.device, dtype=torch.float32)
+                lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gpad), 1, 0, _st())
+                gx = torch.empty_like(x)
+                lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
+            else:
+                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
+                gx = torch.empty_like(x)
+                lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
+        if ctx.needs_input_grad[1]:
+            d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+            gwf = torch.zeros_like(wf)
+            lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), 1, 0, _st())
+        if ctx.has[0] and ctx.needs_input_grad[2]:
+            gb = torch.zeros(k, device=x.device, dtype=torch.float32)
+            lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
+        if ctx.has[1] and ctx.needs_input_grad[3]:
+            gres = gy
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None
+
+
+def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE):
+    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act)
+
+
+class _ConvTranspose2d(torch.autograd.Function):
+    """ConvTranspose2d as the adjoint of the stride-s conv that maps the big image onto the small one.
+    x [N,h,w,Cs]; packed weights are those of the conv view (rows = Cs, C = Cb)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, out_pad):
+        _chk(x, wf, bias, residual)
+        lib = _L()
+        n, h, w, cs = x.shape
+        cb = wf.shape[1]
+        H = (h - 1) * stride - 2 * pad + kh + out_pad
+        W = (w - 1) * stride - 2 * pad + kw + out_pad
+        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        if (oh, ow) != (h, w):
+            raise FmiError("unsupported ConvTranspose2d geometry")
+        y = torch.empty((n, H, W, cb), device=x.device, dtype=torch.float32)
+        lib.conv2d_dgrad_f32(C.byref(d), _p(x), _p(wt), _p(bias), _p(residual), _p(y), 1, 0, _st())
+        ctx.save_for_backward(x, wf)
+        ctx.cfg, ctx.has, ctx.HW = (kh, kw, stride, pad), (bias is not None, residual is not None), (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _L()
+        x, wf = ctx.saved_tensors
+        kh, kw, stride, pad = ctx.cfg
+        H, W = ctx.HW
+        gy = gy.contiguous()
+        n, h, w, cs = x.shape
+        cb = wf.shape[1]
+        d, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        gx = gwf = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
+        if ctx.needs_input_grad[1]:
+            gwf = torch.zeros_like(wf)
+            lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), 1, 0, _st())
+        if ctx.has[0] and ctx.needs_input_grad[2]:
+            gb = torch.zeros(cb, device=x.device, dtype=torch.float32)
+            lib.bias_grad_f32(_p(gy), gy.numel() // cb, cb, cb, _p(gb), _st())
+        if ctx.has[1] and ctx.needs_input_grad[3]:
+            gres = gy
+        return gx, gwf, gb, gres, None, None, None, None, None, None
+
+
+def conv_transpose2d(x, pw: PackedWeight, bias=None, residual=None, stride=2, pad=1, out_pad=1):
+    return _ConvTranspose2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, out_pad)
+
+
+# ---------------------------------------------------------------------------------------------------
+# element-wise / pooling / normalisation
+# ---------------------------------------------------------------------------------------------------
+class _LeakyReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return eltwise(EW_LRELU, x, None, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return eltwise(EW_LRELU_BWD, g.contiguous(), x, ctx.slope), None
+
+
+def leaky_relu(x, slope=0.1):
+    return _LeakyReLU.apply(x, slope)
+
+
+class _Softplus(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return eltwise(EW_SOFTPLUS, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return eltwise(EW_SOFTPLUS_BWD, g.contiguous(), x)
+
+
+class _MulAdd(torch.autograd.Function):
+    """a * b + c with b a constant (the re-parameterisation noise)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.save_for_backward(b)
+        return eltwise(EW_ADD, eltwise(EW_MUL, a, b), c)
+
+    @staticmethod
+    def backward(ctx, g):
+        (b,) = ctx.saved_tensors
+        g = g.contiguous()
+        return eltwise(EW_MUL, g, b), None, g
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return eltwise(EW_ADD, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        _chk(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // k, w // k, c), device=x.device, dtype=torch.float32)
+        _L().avgpool_f32(_p(x), _p(y), n, h, w, c, k, _st())
+        ctx.shape, ctx.k = x.shape, k
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _L().avgpool_bwd_f32(_p(g.contiguous()), _p(gx), n, h, w, c, ctx.k, _st())
+        return gx, None
+
+
+def avg_pool(x, k=2):
+    return _AvgPool.apply(x, k)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // 2, w // 2, c), device=x.device, dtype=torch.float32)
+        _L().maxpool2_f32(_p(x), _p(y), n, h, w, c, _st())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        gx = torch.empty_like(x)
+        _L().maxpool2_bwd_f32(_p(x), _p(g.contiguous()), _p(gx), n, h, w, c, _st())
+        return gx
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow, mean, std):
+        _chk(x, mean, std)
+        n, h, w, c = x.shape
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        _L().resize_bilinear_f32(_p(x), _p(y), n, h, w, c, oh, ow, _p(mean), _p(std), _st())
+        ctx.shape, ctx.std = x.shape, std
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        gx = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
+        _L().resize_bilinear_bwd_f32(_p(g.contiguous()), _p(gx), n, h, w, c, g.shape[1], g.shape[2], _p(ctx.std), _st())
+        return gx, None, None, None, None
+
+
+def resize_bilinear(x, oh, ow, mean=None, std=None):
+    """bilinear, align_corners=True, optionally followed by (v - mean[c]) / std[c]."""
+    return _Resize.apply(x, oh, ow, mean, std)
+
+
+class _InstNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        _chk(x, gamma, beta)
+        lib = _L()
+        n, h, w, c = x.shape
+        sums = torch.zeros((n, c, 2), device=x.device, dtype=torch.float64)
+        stats = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
+        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), n, h * w, c, eps, _st())
+        y = torch.empty_like(x)
+        lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), n, h * w, c, slope, _st())
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _L()
+        x, stats, gamma, beta = ctx.saved_tensors
+        n, h, w, c = x.shape
+        g = g.contiguous()
+        red = torch.zeros((n, c, 2), device=x.device, dtype=torch.float64)
+        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), n, h * w, c, ctx.slope, _st())
+        gx = torch.empty_like(x)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(beta)
+        lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
+                                   n, h * w, c, ctx.slope, _st())
+        return gx, dg, db, None, None
+
+
+def instance_norm_act(x, gamma, beta, eps=1e-5, slope=1.0):
+    """lrelu(InstanceNorm2d(affine)(x)); slope = 1 disables the activation."""
+    return _InstNormAct.apply(x, gamma, beta, eps, slope)
+
+
+class _MaskMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, invert):
+        _chk(x, m)
+        y = torch.empty_like(x)
+        c = x.shape[-1]
+        _L().mask_mul_f32(_p(x), _p(m), _p(y), x.numel() // c, c, invert, _st())
+        ctx.save_for_backward(m)
+        ctx.invert = invert
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        c = g.shape[-1]
+        _L().mask_mul_f32(_p(g), _p(m), _p(gx), g.numel() // c, c, ctx.invert, _st())
+        return gx, None, None
+
+
+def mask_mul(x, m, invert=False):
+    """x[N,H,W,C] * m[N,H,W] (or 1-m)."""
+    return _MaskMul.apply(x, m, 1 if invert else 0)
+
+
+def binarise_mask(mask_i64: torch.Tensor) -> torch.Tensor:
+    """(mask > 0).float() -- train_reference_fill.py:340; bit exact."""
+    if not mask_i64.is_cuda or mask_i64.dtype != torch.int64:
+        raise FmiError("binarise_mask needs an int64 device tensor")
+    m = mask_i64.contiguous()
+    out = torch.empty(m.shape, device=m.device, dtype=torch.float32)
+    _L().mask_binarise_i64(C.c_void_p(m.data_ptr()), _p(out), m.numel(), _st())
+    return out
+
+
+class _GuideBlend(torch.autograd.Function):
+    """out[..., :C] = (1-m) ref_att + m ref ; out[..., C:] = src_att   (example_guided_att.py:35-37)."""
+
+    @staticmethod
+    def forward(ctx, ref_att, ref, src_att, m):
+        _chk(ref_att, ref, src_att, m)
+        n, h, w, c = ref.shape
+        out = torch.empty((n, h, w, 2 * c), device=ref.device, dtype=torch.float32)
+        _L().guide_blend_f32(_p(ref_att), _p(ref), _p(m), _p(out), n * h * w, c, 2 * c, _st())
+        out[..., c:] = src_att
+        ctx.save_for_backward(m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        g = g.contiguous()
+        n, h, w, c2 = g.shape
+        c = c2 // 2
+        gra = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
+        grf = torch.empty_like(gra)
+        _L().guide_blend_bwd_f32(_p(g), _p(m), _p(gra), _p(grf), n * h * w, c, c2, _st())
+        return gra, grf, g[..., c:].contiguous(), None
+
+
+def guide_blend_cat(ref_att, ref, src_att, m):
+    return _GuideBlend.apply(ref_att, ref, src_att, m)
+
+
+class _ScaleAddParam(torch.autograd.Function):
+    """y = gamma * o + x with gamma a 1-element device parameter (base_function.py:439)."""
+
+    @staticmethod
+    def forward(ctx, o, gamma, x):
+        _chk(o, gamma, x)
+        y = torch.empty_like(x)
+        _L().axpy_dev_f32(_p(o), _p(gamma), _p(x), _p(y), x.numel(), _st())
+        ctx.save_for_backward(o, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        o, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        go = torch.empty_like(g)
+        _L().axpy_dev_f32(_p(g), _p(gamma), None, _p(go), g.numel(), _st())
+        gg = torch.zeros_like(gamma)
+        _L().dot_f32(_p(g), _p(o), g.numel(), 1.0, _p(gg), _st())
+        return go, gg, g
+
+
+def scale_add_param(o, gamma, x):
+    return _ScaleAddParam.apply(o, gamma, x)
+
+
+class _VaeSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, o_src, o_ref, eps_q, eps_p):
+        _chk(o_src, o_ref, eps_q, eps_p)
+        n, h, w, c2 = o_src.shape
+        z = torch.empty_like(o_src)
+        _L().vae_sample_f32(_p(o_src), _p(o_ref), _p(eps_q), _p(eps_p), _p(z), n * h * w, c2 // 2, _st())
+        ctx.save_for_backward(o_src, o_ref, eps_q, eps_p)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        o_src, o_ref, eps_q, eps_p = ctx.saved_tensors
+        n, h, w, c2 = o_src.shape
+        gs, gr = torch.empty_like(o_src), torch.empty_like(o_ref)
+        _L().vae_sample_bwd_f32(_p(g.contiguous()), _p(o_src), _p(o_ref), _p(eps_q), _p(eps_p), _p(gs), _p(gr), n * h * w, c2 // 2, _st())
+        return gs, gr, None, None
+
+
+def vae_sample(o_src, o_ref, eps_q, eps_p):
+    """z = cat[mu_q + softplus(s_q) eps_q, mu_p + softplus(s_p) eps_p] (network.py:167-168,275-307)."""
+    return _VaeSample.apply(o_src, o_ref, eps_q, eps_p)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention:  A = softmax(Q Q^T) ;  O_i = A V_i        (Q [N,T,d], V_i [N,T,C_i])
+# chunked over query rows so that one score chunk stays inside the Infinity Cache
+# ---------------------------------------------------------------------------------------------------
+def _attn_chunk(n, t):
+    rows = ATTN_CHUNK_BYTES // (n * t * 4)
+    rows = max(128, (rows // 128) * 128)
+    return min(t, rows)
+
+
+def _scores(q, n, t, d, q0, qc, buf):
+    # S[b, i, j] = q[b, q0+i, :] . q[b, j, :]
+    gemm_raw(_p(q, q0 * d), _p(q), _p(buf), qc, t, d, (d, 1), (1, d), (t, 1), n, (t * d, t * d, qc * t))
+    _L().softmax_rows_f32(_p(buf), _p(buf), n * qc, t, _st())
+
+
+class _SelfAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, *vs):
+        _chk(q, *vs)
+        n, t, d = q.shape
+        qc_max = _attn_chunk(n, t)
+        buf = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
+        outs = [torch.empty_like(v) for v in vs]
+        for q0 in range(0, t, qc_max):
+            qc = min(qc_max, t - q0)
+            _scores(q, n, t, d, q0, qc, buf)
+            for v, o in zip(vs, outs):
+                c = v.shape[2]
+                gemm_raw(_p(buf), _p(v), _p(o, q0 * c), qc, c, t, (t, 1), (c, 1), (c, 1), n, (qc * t, t * c, t * c))
+        ctx.save_for_backward(q, *vs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gos):
+        q, *vs = ctx.saved_tensors
+        n, t, d = q.shape
+        qc_max = max(128, (_attn_chunk(n, t) // 2 // 128) * 128)
+        qc_max = min(t, qc_max)
+        P = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
+        dP = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
+        gos = [g.contiguous() if g is not None else None for g in gos]
+        gq = torch.zeros_like(q)
+        gvs = [torch.zeros_like(v) if g is not None else None for v, g in zip(vs, gos)]
+        for q0 in range(0, t, qc_max):
+            qc = min(qc_max, t - q0)
+            _scores(q, n, t, d, q0, qc, P)
+            first = True
+            for v, g, gv in zip(vs, gos, gvs):
+                if g is None:
+                    continue
+                c = v.shape[2]
+                # dV += P^T dO_chunk
+                gemm_raw(_p(P), _p(g, q0 * c), _p(gv), t, c, qc, (1, t), (c, 1), (c, 1), n, (qc * t, t * c, t * c), 1.0, 1.0)
+                # dP (+)= dO_chunk V^T
+                gemm_raw(_p(g, q0 * c), _p(v), _p(dP), qc, t, c, (c, 1), (1, c), (t, 1), n, (t * c, t * c, qc * t), 1.0, 0.0 if first else 1.0)
+                first = False
+            if first:
+                continue
+            _L().softmax_rows_bwd_f32(_p(P), _p(dP), _p(dP), n * qc, t, _st())
+            # query side: dQ[chunk] += dS Q ; key side: dQ += dS^T Q[chunk]
+            gemm_raw(_p(dP), _p(q), _p(gq, q0 * d), qc, d, t, (t, 1), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0)
+            gemm_raw(_p(dP), _p(q, q0 * d), _p(gq), t, d, qc, (1, t), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0)
+        return (gq,) + tuple(gvs)
+
+
+def self_attention(q: torch.Tensor, values: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, ...]:
+    """q [N,T,d]; values: list of [N,T,C]; returns softmax(q q^T) @ v for each v."""
+    return _SelfAttention.apply(q, *values)
+
+
+# ---------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------
+class _ReduceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, a, b, c0, scale):
+        _chk(a, b)
+        out = torch.zeros((), device=a.device, dtype=torch.float32)
+        _L().reduce_loss_f32(kind, _p(a), _p(b), a.numel(), c0, scale, _p(out), _st())
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (kind, c0, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        kind, c0, scale = ctx.cfg
+        ga = torch.empty_like(a)
+        _L().reduce_loss_bwd_f32(kind, _p(a), _p(b), a.numel(), c0, scale, _p(g.contiguous()), _p(ga), _st())
+        gb = None
+        if b is not None and ctx.needs_input_grad[2]:
+            gb = eltwise(EW_SCALE, ga, None, -1.0)
+        return None, ga, gb, None, None
+
+
+def l1_loss(a, b):
+    """mean |a - b| (nn.L1Loss / F.l1_loss)."""
+    return _ReduceLoss.apply(0, a.contiguous(), b.contiguous(), 0.0, 1.0 / a.numel())
+
+
+def mse_loss(a, b):
+    return _ReduceLoss.apply(1, a.contiguous(), b.contiguous(), 0.0, 1.0 / a.numel())
+
+
+def mse_to_const(a, c0):
+    """mean (a - c0)^2: LSGAN objective against a constant label (external_function.py:113-115)."""
+    return _ReduceLoss.apply(2, a.contiguous(), None, float(c0), 1.0 / a.numel())
+
+
+class _Gram(torch.autograd.Function):
+    """G[n] = X[n]^T X[n] / (C*P), X [N,P,C]   (external_function.py:180-185)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        n, p, c = x.shape
+        g = torch.empty((n, c, c), device=x.device, dtype=torch.float32)
+        gemm_raw(_p(x), _p(x), _p(g), c, c, p, (1, c), (c, 1), (c, 1), n, (p * c, p * c, c * c), 1.0 / (c * p))
+        ctx.save_for_backward(x)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (x,) = ctx.saved_tensors
+        n, p, c = x.shape
+        dg = dg.contiguous()
+        gx = torch.empty_like(x)
+        a = 1.0 / (c * p)
+        # dX = a * X (dG + dG^T)
+        gemm_raw(_p(x), _p(dg), _p(gx), p, c, c, (c, 1), (c, 1), (c, 1), n, (p * c, c * c, p * c), a, 0.0)
+        gemm_raw(_p(x), _p(dg), _p(gx), p, c, c, (c, 1), (1, c), (c, 1), n, (p * c, c * c, p * c), a, 1.0)
+        return gx
+
+
+def gram_matrix(x_npc):
+    return _Gram.apply(x_npc)
+
+
+class _ContextualLoss(torch.autograd.Function):
+    """external_function.py:231-274 on NHWC features flattened to [N,P,C]; y carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, y, h, scale):
+        _chk(x, y)
+        lib = _L()
+        n, p, c = x.shape
+        dev = x.device
+        mu = torch.zeros(c, device=dev, dtype=torch.float32)
+        lib.cx_channel_mean_f32(_p(y), _p(mu), n * p, c, _st())
+        xn, yn = torch.empty_like(x), torch.empty_like(y)
+        xi, yi = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
+        lib.cx_normalise_f32(_p(x), _p(mu), _p(xn), _p(xi), n * p, c, _st())
+        lib.cx_normalise_f32(_p(y), _p(mu), _p(yn), _p(yi), n * p, c, _st())
+        cosm = torch.empty((n, p, p), device=dev, dtype=torch.float32)
+        gemm_raw(_p(xn), _p(yn), _p(cosm), p, p, c, (c, 1), (1, c), (p, 1), n, (p * c, p * c, p * p))
+        cxij = torch.empty_like(cosm)
+        dmin = torch.empty(n * p, device=dev)
+        amin = torch.empty(n * p, device=dev, dtype=torch.int32)
+        rsum = torch.empty(n * p, device=dev)
+        lib.cx_rows_f32(_p(cosm), _p(cxij), _p(dmin), C.c_void_p(amin.data_ptr()), _p(rsum), n, p, h, _st())
+        cmax = torch.empty(n * p, device=dev)
+        carg = torch.empty(n * p, device=dev, dtype=torch.int32)
+        lib.cx_cols_f32(_p(cxij), _p(cmax), C.c_void_p(carg.data_ptr()), n, p, _st())
+        cx = torch.empty(n, device=dev)
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        lib.cx_loss_f32(_p(cmax), _p(cx), _p(loss), n, p, scale, _st())
+        ctx.save_for_backward(xn, yn, xi, cosm, cxij, dmin, amin, rsum, carg, cx)
+        ctx.cfg = (h, scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _L()
+        xn, yn, xi, cosm, cxij, dmin, amin, rsum, carg, cx = ctx.saved_tensors
+        h, scale = ctx.cfg
+        n, p, c = xn.shape
+        dcos = torch.empty_like(cosm)
+        lib.cx_bwd_f32(_p(cxij), _p(dmin), C.c_void_p(amin.data_ptr()), _p(rsum), _p(cosm), C.c_void_p(carg.data_ptr()), _p(cx),
+                       _p(g.contiguous()), _p(dcos), n, p, h, scale, _st())
+        gxn = torch.empty_like(xn)
+        gemm_raw(_p(dcos), _p(yn), _p(gxn), p, c, p, (p, 1), (c, 1), (c, 1), n, (p * p, p * c, p * c))
+        gx = torch.empty_like(xn)
+        lib.cx_normalise_bwd_f32(_p(gxn), _p(xn), _p(xi), _p(gx), n * p, c, _st())
+        return gx, None, None, None
+
+
+def contextual_loss(x_npc, y_npc, h=0.5, scale=1.0):
+    return _ContextualLoss.apply(x_npc.contiguous(), y_npc.contiguous(), h, scale)
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-tensor Adam
+# ---------------------------------------------------------------------------------------------------
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay=0.0):
+    n = len(params)
+    if n == 0:
+        return
+    entries = (_lib.AdamEntry * n)()
+    mx = 0
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        _chk(p, g, m, v)
+        e = entries[i]
+        e.p, e.g, e.m, e.v, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        mx = max(mx, p.numel())
+    _L().adam_step_f32(entries, n, mx, lr, beta1, beta2, eps, weight_decay, step, _st())

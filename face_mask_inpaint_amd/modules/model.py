@@ -1,0 +1,66 @@
+"""Host-side mirror of modules/model.py: ReferenceFill (model.py:15-112) and scale_img (model.py:10-12)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import functional as FF
+from ..weights import weight_scope
+from .example_guided_att import ExampleGuidedAttention
+from .pluralistic_model import network
+
+
+def scale_img(img, size):
+    """bilinear, align_corners=True on an NCHW-shaped tensor (model.py:10-12)."""
+    return FF.to_nchw(FF.resize_bilinear(FF.to_nhwc(img), int(size[0]), int(size[1])))
+
+
+class ReferenceFill(nn.Module):
+    def __init__(self, mask_detector, encoder_params, decoder_params, use_att=True, out_size=(256, 256)):
+        super().__init__()
+        self.mask_detector = mask_detector
+        self.encoder_type = encoder_params.pop("type")
+        if self.encoder_type != "pluralistic":
+            raise NotImplementedError("only encoder type 'pluralistic' is on the hot path (DRN: SURVEY.md section 2 row 14)")
+        self.src_encoder = network.define_e(**encoder_params, encoder_type="src")
+        self.ref_encoder = network.define_e(**encoder_params, encoder_type="ref")
+        self.decoder = network.define_g(**decoder_params)
+        self.use_att = use_att
+        if use_att:
+            self.attention = ExampleGuidedAttention(encoder_params["img_f"])
+        self.pool = nn.AdaptiveAvgPool2d(out_size)
+        self._out_size = tuple(out_size)
+
+    def forward(self, src_image, ref_image, src_mask=None, resize=True, no_prior=False, eps=None):
+        """src_image / ref_image [N,3,H,W]; src_mask [N,H,W] float {0,1}.  ``eps = (eps_p, eps_q)`` optionally injects
+        the two standard-normal draws of get_z ([N, z_nc, h, w], posterior first); default: fresh torch.randn draws."""
+        if src_mask is None:
+            if self.mask_detector is None:
+                raise ValueError("src_mask is required when no mask_detector is attached")
+            src_mask = self.mask_detector(src_image, mode="eval")
+        if no_prior or not self.use_att:
+            raise NotImplementedError("no_prior / use_att=False variants are not on the benchmarked path")
+        with weight_scope(self):
+            src = FF.to_nhwc(src_image)
+            ref = FF.to_nhwc(ref_image)
+            o_src, src_feat = self.src_encoder.nhwc_raw(src)
+            o_ref, ref_feat = self.ref_encoder.nhwc_raw(ref)
+            n, fh, fw, _ = src_feat.shape
+            m = FF.resize_bilinear(src_mask.contiguous().unsqueeze(-1), fh, fw).view(n, fh, fw)
+            enc = self.attention.nhwc(m, src_feat, ref_feat)
+            z_nc = o_src.shape[-1] // 2
+            if eps is None:
+                eps_p = torch.randn((n, fh, fw, z_nc), device=src.device)
+                eps_q = torch.randn((n, fh, fw, z_nc), device=src.device)
+            else:
+                eps_p, eps_q = FF.to_nhwc(eps[0]), FF.to_nhwc(eps[1])
+            z = FF.vae_sample(o_src, o_ref, eps_q, eps_p)
+            img = self.decoder.nhwc(enc, z)
+            if resize:
+                oh, ow = self._out_size
+                ih, iw = img.shape[1], img.shape[2]
+                if ih % oh or iw % ow or ih // oh != iw // ow:
+                    raise NotImplementedError("AdaptiveAvgPool2d is implemented for integer pooling factors (1024 -> 256)")
+                if ih // oh > 1:
+                    img = FF.avg_pool(img, ih // oh)
+            return FF.to_nchw(img)

@@ -111,7 +111,8 @@ typedef struct {
   float* sigma;     /* out [1] (may be NULL when u == NULL) */
   int rows, C, taps, pad_;
 } fmi_weight_entry;
-int fmi_weight_prepare_f32(const fmi_weight_entry* entries_dev, int count, void* stream);
+/* entries: HOST array (pointers inside are device pointers); passed to the kernels by value, <= 32 per launch */
+int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count, void* stream);
 
 typedef struct {
   const float* w;      /* [rows][C*taps] */
@@ -122,7 +123,7 @@ typedef struct {
   float* dw;           /* out [rows][C*taps], overwritten */
   int rows, C, taps, pad_;
 } fmi_weight_grad_entry;
-int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries_dev, int count, void* stream);
+int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, void* stream);  /* HOST array */
 
 /* ------------------------------------------------------------------------
  * Row softmax over the last dimension (base_function.py:412,430,
@@ -150,7 +151,7 @@ enum {
   FMI_EW_COUNT_
 };
 int fmi_eltwise_f32(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream);
-/* y = a * s[0] + b, s is a 1-element DEVICE tensor (Auto_Attn gamma, base_function.py:439) */
+/* y = a * s[0] + b (b may be NULL), s is a 1-element DEVICE tensor (Auto_Attn gamma, base_function.py:439) */
 int fmi_axpy_dev_f32(const float* a, const float* s, const float* b, float* y, int64_t n, void* stream);
 /* out[0] += scale * sum(a*b)  (caller zeroes out) */
 int fmi_dot_f32(const float* a, const float* b, int64_t n, float scale, float* out, void* stream);
@@ -181,13 +182,13 @@ int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, 
 /* 2x2 max pooling (VGG16 features, loss.py:21-25); backward routes to the first maximum */
 int fmi_maxpool2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int fmi_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C, void* stream);
-/* bilinear, align_corners=True (model.py:10-12) with optional per-channel affine y = s*v + t
- * (VGG input normalisation loss.py:51-52); in/out NHWC */
+/* bilinear, align_corners=True (model.py:10-12) with the optional per-channel normalisation
+ * y = (v - mean[c]) / std[c] of the VGG input (loss.py:51-52) fused in; in/out NHWC */
 int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
-                            const float* ch_scale, const float* ch_shift, void* stream);
+                            const float* ch_mean, const float* ch_std, void* stream);
 /* gx += ... (atomic scatter; caller zeroes gx) */
 int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW,
-                                const float* ch_scale, void* stream);
+                                const float* ch_std, void* stream);
 /* InstanceNorm2d(affine) (base_function.py:47): stats[n][c] = {mean, rstd}; y = act((x-mean)*rstd*g + b),
  * act = LeakyReLU(slope) fused when slope != 1. */
 int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2] zeroed*/, float* stats /*[N][C][2]*/,
@@ -211,9 +212,7 @@ int fmi_reduce_loss_f32(int kind, const float* a, const float* b, int64_t n, flo
 /* gradient of the above w.r.t. a: ga = gscale[0]*scale * d/da ; gscale is a DEVICE scalar (upstream grad) */
 int fmi_reduce_loss_bwd_f32(int kind, const float* a, const float* b, int64_t n, float c0, float scale,
                             const float* gscale, float* ga, void* stream);
-/* gsym[b][i][j] = coef * (sgn(ga-gb)[i][j] + sgn(ga-gb)[j][i]) * gscale[0]  for the Gram/L1 style loss */
-int fmi_gram_l1_bwd_f32(const float* ga, const float* gb, float* gsym, int batch, int C, float coef,
-                        const float* gscale, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * Contextual loss (external_function.py:231-274), x,y NHWC features [N,P,C].
@@ -223,12 +222,12 @@ int fmi_cx_channel_mean_f32(const float* y, float* mu /*[C] zeroed*/, int64_t ro
 int fmi_cx_normalise_f32(const float* x, const float* mu, float* out, float* inv_norm, int64_t rows, int C, void* stream);
 int fmi_cx_normalise_bwd_f32(const float* g, const float* xn, const float* inv_norm, float* gx, int64_t rows, int C, void* stream);
 /* from cos[N][P][P] (row i = x point, col j = y point): per-row d_min, w = exp((1 - d/(dmin+1e-5))/h), row sums;
- * cxij = w/rowsum written in place; colmax[n][j] + argmax over i; cx[n] = mean_j colmax; loss += -log(cx+1e-5)/N */
-int fmi_cx_rows_f32(float* cos_inout, float* dmin, int* argmin, float* rowsum, int N, int P, float h, void* stream);
+ * cxij = w/rowsum; colmax[n][j] + argmax over i; cx[n] = mean_j colmax; loss += scale * -log(cx+1e-5)/N */
+int fmi_cx_rows_f32(const float* cosm, float* cxij, float* dmin, int* argmin, float* rowsum, int N, int P, float h, void* stream);
 int fmi_cx_cols_f32(const float* cxij, float* colmax, int* colarg, int N, int P, void* stream);
 int fmi_cx_loss_f32(const float* colmax, float* cx /*[N]*/, float* loss /*[1] zeroed*/, int N, int P, float scale, void* stream);
 /* backward: writes dcos[N][P][P] (overwrites) */
-int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* argmin, const float* rowsum, const float* cos_unused,
+int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* argmin, const float* rowsum, const float* cosm,
                    const int* colarg, const float* cx, const float* gscale, float* dcos, int N, int P, float h, float scale,
                    void* stream);
 
@@ -238,7 +237,7 @@ int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* argmin, cons
 typedef struct {
   float* p; const float* g; float* m; float* v; int64_t n;
 } fmi_adam_entry;
-int fmi_adam_step_f32(const fmi_adam_entry* entries_dev, int count, int64_t max_n, float lr, float beta1, float beta2,
+int fmi_adam_step_f32(const fmi_adam_entry* entries /* HOST array */, int count, int64_t max_n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, void* stream);
 
 /* ------------------------------------------------------------------------

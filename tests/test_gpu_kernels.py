@@ -1,0 +1,415 @@
+"""GPU: every HIP kernel through the C ABI against plain torch fp32 (CPU) on the same seeded inputs.
+Tolerances are stated per test; index / integer work is bit exact."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def FF():
+    from face_mask_inpaint_amd import functional
+
+    return functional
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def pack(w):
+    k, c, kh, kw = w.shape
+    return (w.permute(2, 3, 1, 0).reshape(kh * kw, c, k).contiguous(), w.permute(2, 3, 0, 1).reshape(kh * kw, k, c).contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k,bsz", [(13, 10, 21, 2), (128, 128, 64, 1), (257, 100, 130, 3), (64, 300, 48, 2), (30, 200, 17, 1), (500, 24, 260, 2)])
+def test_gemm(dev, FF, ta, tb, m, n, k, bsz):
+    """fp32 MFMA = fmaf chain: error ~1e-7 * sum|a b| -> rtol 1e-5 at K <= 260"""
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(bsz, m, k, generator=g)
+    b = torch.randn(bsz, k, n, generator=g)
+    c0 = torch.randn(bsz, m, n, generator=g)
+    bias = torch.randn(n, generator=g)
+    am = (a.transpose(1, 2).contiguous() if ta else a.contiguous()).to(dev)
+    bm = (b.transpose(1, 2).contiguous() if tb else b.contiguous()).to(dev)
+    sa = (1, m) if ta else (k, 1)
+    sb = (1, k) if tb else (n, 1)
+    c = c0.clone().to(dev)
+    biasd = bias.to(dev)
+    FF.gemm_raw(FF._p(am), FF._p(bm), FF._p(c), m, n, k, sa, sb, (n, 1), bsz, (m * k, k * n, m * n), 0.5, 2.0, biasd)
+    ref = 0.5 * (a.double() @ b.double()) + bias.double() + 2.0 * c0.double()
+    torch.testing.assert_close(c.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_mfma_layout_asymmetric(dev, FF):
+    """A = I against an asymmetric integer B catches swapped row/column fragment maps exactly."""
+    n = 96
+    a = torch.eye(n)
+    b = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97) - 5.0
+    c = torch.zeros(n, n, device=dev)
+    ad, bd = a.to(dev), b.to(dev)
+    FF.gemm_raw(FF._p(ad), FF._p(bd), FF._p(c), n, n, n, (n, 1), (n, 1), (n, 1))
+    assert torch.equal(c.cpu(), b)
+
+
+CONV_CASES = [  # n, c, k, h, w, ksz, stride, pad
+    (2, 8, 12, 9, 7, 3, 1, 1), (1, 3, 8, 10, 11, 3, 1, 1), (2, 16, 5, 6, 6, 1, 1, 0), (2, 8, 4, 12, 10, 3, 2, 1),
+    (1, 4, 6, 9, 8, 4, 2, 1), (2, 8, 1, 7, 7, 3, 1, 0), (2, 32, 64, 33, 31, 3, 1, 1), (1, 64, 32, 40, 40, 3, 1, 1),
+    (2, 128, 128, 16, 16, 3, 1, 1), (1, 32, 3, 64, 64, 3, 1, 1), (2, 256, 64, 8, 8, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", CONV_CASES)
+def test_conv_family(dev, FF, n, c, k, h, w, ksz, stride, pad):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(h * 100 + c)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt_ = (torch.randn(k, c, ksz, ksz, generator=g) / (c * ksz * ksz) ** 0.5).requires_grad_(True)
+    b = torch.randn(k, generator=g)
+    y = F.conv2d(x, wt_, b, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad)
+    wf, wtp = [t.to(dev) for t in pack(wt_.detach())]
+    xh, gyh, bd = nhwc(x.detach()).to(dev), nhwc(gy).to(dev), b.to(dev)
+    res = torch.randn(n, oh, ow, k, generator=g)
+    resd = res.to(dev)
+    out = torch.full((n, oh, ow, k), float("nan"), device=dev)
+    st = FF._st()
+    lib.conv2d_fwd_f32(C.byref(d), FF._p(xh), FF._p(wf), FF._p(bd), FF._p(resd), FF._p(out), 0, 1, 0, st)
+    torch.testing.assert_close(out.cpu(), nhwc(y.detach()) + res, rtol=1e-4, atol=1e-5)
+    dx = torch.full((n, h, w, c), float("nan"), device=dev)
+    lib.conv2d_dgrad_f32(C.byref(d), FF._p(gyh), FF._p(wtp), None, None, FF._p(dx), 1, 0, st)
+    torch.testing.assert_close(dx.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
+    dwf = torch.zeros_like(wf)
+    lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf), 1, 0, st)
+    torch.testing.assert_close(dwf.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=2e-4)
+    db = torch.zeros(k, device=dev)
+    lib.bias_grad_f32(FF._p(gyh), n * oh * ow, k, k, FF._p(db), st)
+    torch.testing.assert_close(db.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+
+
+def test_conv_transpose_and_autograd(dev, FF):
+    g = torch.Generator().manual_seed(0)
+    cs, cb, hs, ws = 16, 8, 9, 11
+    x = torch.randn(2, cs, hs, ws, generator=g, requires_grad=True)
+    w = (torch.randn(cs, cb, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(cb, generator=g, requires_grad=True)
+    y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+    wd = w.detach().to(dev).requires_grad_(True)
+    bd = b.detach().to(dev).requires_grad_(True)
+    (pw,) = FF.prepare_weights([(wd, None, None)])
+    out = FF.conv_transpose2d(xd, pw, bd)
+    torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-4, atol=1e-5)
+    out.backward(nhwc(gy).to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_reflect_conv_tanh_autograd(dev, FF):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 8, 9, 7, generator=g, requires_grad=True)
+    w = (torch.randn(3, 8, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(3, generator=g, requires_grad=True)
+    y = torch.tanh(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+    wd, bd = w.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    (pw,) = FF.prepare_weights([(wd, None, None)])
+    out = FF.conv2d(xd, pw, bd, None, 1, 1, 1, FF.ACT_TANH)
+    torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-4, atol=1e-5)
+    out.backward(nhwc(gy).to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_spectral_norm_prepare_and_grad(dev, FF):
+    """one power iteration + W/sigma + packing, and the gradient through sigma (external_function.py:30-41)"""
+    g = torch.Generator().manual_seed(2)
+    for shape in [(16, 8, 3, 3), (8, 24, 1, 1), (64, 32, 3, 3)]:
+        w = torch.randn(*shape, generator=g, requires_grad=True)
+        h = shape[0]
+        u0 = F.normalize(torch.randn(h, generator=g), dim=0)
+        v0 = F.normalize(torch.randn(w[0].numel(), generator=g), dim=0)
+        wm = w.detach().reshape(h, -1)
+        v1 = wm.t().mv(u0)
+        v1 = v1 / (v1.norm() + 1e-12)
+        u1 = wm.mv(v1)
+        u1 = u1 / (u1.norm() + 1e-12)
+        sigma = u1.dot(w.reshape(h, -1).mv(v1))
+        weff = w / sigma
+        gw = torch.randn(*shape, generator=g)
+        weff.backward(gw)
+        wd = w.detach().to(dev).requires_grad_(True)
+        ud, vd = u0.to(dev), v0.to(dev)
+        (pw,) = FF.prepare_weights([(wd, ud, vd)])
+        torch.testing.assert_close(ud.cpu(), u1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(vd.cpu(), v1, rtol=1e-5, atol=1e-6)
+        wf_ref, wt_ref = pack(weff.detach())
+        torch.testing.assert_close(pw.wf.detach().cpu(), wf_ref, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pw.wt.cpu(), wt_ref, rtol=1e-5, atol=1e-6)
+        pw.wf.backward(pack(gw)[0].to(dev))
+        torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_eltwise_and_softplus(dev, FF):
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(3, 5, 7, 9, generator=g) * 3
+    b = torch.randn(3, 5, 7, 9, generator=g)
+    ad, bd = a.to(dev), b.to(dev)
+    cases = {
+        FF.EW_LRELU: F.leaky_relu(a, 0.1), FF.EW_LRELU_BWD: a * torch.where(b > 0, 1.0, 0.1), FF.EW_TANH_BWD: a * (1 - b * b),
+        FF.EW_ADD: a + b, FF.EW_SCALE: a * 0.1, FF.EW_AXPY: 0.1 * a + b, FF.EW_MUL: a * b, FF.EW_RELU_BWD_OUT: a * (b > 0),
+        FF.EW_SOFTPLUS: F.softplus(a), FF.EW_SOFTPLUS_BWD: a * torch.sigmoid(b), FF.EW_SUB: a - b,
+    }
+    for op, ref in cases.items():
+        out = FF.eltwise(op, ad, bd, 0.1)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6, msg=lambda m, op=op: f"op {op}: {m}")
+    big = torch.tensor([25.0, -30.0, 19.99, 20.01], device=dev)
+    torch.testing.assert_close(FF.eltwise(FF.EW_SOFTPLUS, big).cpu(), F.softplus(big.cpu()), rtol=1e-6, atol=1e-7)
+
+
+def test_pools_and_resize(dev, FF):
+    g = torch.Generator().manual_seed(4)
+    for c in (8, 3):
+        x = torch.randn(2, c, 12, 8, generator=g, requires_grad=True)
+        for k in (2, 4):
+            y = F.avg_pool2d(x, k, k)
+            gy = torch.randn(y.shape, generator=g)
+            (gx,) = torch.autograd.grad(y, x, gy)
+            xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+            out = FF.avg_pool(xd, k)
+            torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-6, atol=1e-6)
+            out.backward(nhwc(gy).to(dev))
+            torch.testing.assert_close(xd.grad.cpu(), nhwc(gx), rtol=1e-6, atol=1e-6)
+        y = F.max_pool2d(x, 2, 2)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+        out = FF.max_pool2(xd)
+        assert torch.equal(out.detach().cpu(), nhwc(y.detach()))
+        out.backward(nhwc(gy).to(dev))
+        torch.testing.assert_close(xd.grad.cpu(), nhwc(gx), rtol=0, atol=0)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    x = torch.rand(2, 3, 40, 36, generator=g, requires_grad=True)
+    for oh, ow in ((28, 28), (40, 36), (5, 7), (50, 44)):
+        y = (F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=True) - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+        gy = torch.randn(y.shape, generator=g)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+        out = FF.resize_bilinear(xd, oh, ow, mean.to(dev), std.to(dev))
+        torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-5, atol=1e-5)
+        out.backward(nhwc(gy).to(dev))
+        torch.testing.assert_close(xd.grad.cpu(), nhwc(gx), rtol=1e-4, atol=1e-5)
+
+
+def test_mask_ops_bit_exact(dev, FF, golden):
+    fx = golden("picnet_ops.pt")["binarise"]
+    assert torch.equal(FF.binarise_mask(fx["mask"].to(dev)).cpu(), fx["out"])
+    g = torch.Generator().manual_seed(5)
+    m = torch.randint(-(2 ** 40), 2 ** 40, (3, 17, 19), generator=g)
+    m[0, 0, :5] = torch.tensor([0, 1, -1, 255, -(2 ** 62)])
+    assert torch.equal(FF.binarise_mask(m.to(dev)).cpu(), (m > 0).float())
+    sc = golden("picnet_ops.pt")["scale_img"]
+    md = sc["mask"].to(dev).permute(0, 2, 3, 1).contiguous()
+    torch.testing.assert_close(FF.resize_bilinear(md, 4, 4).cpu().permute(0, 3, 1, 2), sc["out"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(FF.resize_bilinear(md, 5, 7).cpu().permute(0, 3, 1, 2), sc["out_odd"], rtol=1e-6, atol=1e-6)
+    x = torch.randn(2, 6, 5, 3, generator=g)
+    mk = (torch.rand(2, 6, 5, generator=g) < 0.5).float()
+    assert torch.equal(FF.mask_mul(x.to(dev), mk.to(dev), True).cpu(), x * (1 - mk).unsqueeze(-1))
+    assert torch.equal(FF.mask_mul(x.to(dev), mk.to(dev), False).cpu(), x * mk.unsqueeze(-1))
+
+
+def test_instance_norm_act(dev, FF):
+    g = torch.Generator().manual_seed(6)
+    for (n, c, h, w, slope) in [(2, 8, 7, 9, 0.1), (2, 64, 33, 31, 0.1), (1, 32, 64, 64, 1.0), (3, 256, 5, 5, 0.1)]:
+        x = (torch.randn(n, c, h, w, generator=g) * 2 + 0.7).requires_grad_(True)
+        ga = (torch.randn(c, generator=g) * 0.5 + 1).requires_grad_(True)
+        be = (torch.randn(c, generator=g) * 0.5).requires_grad_(True)
+        y = F.leaky_relu(F.instance_norm(x, weight=ga, bias=be, eps=1e-5), slope)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xd = nhwc(x.detach()).to(dev).requires_grad_(True)
+        gd, bd = ga.detach().to(dev).requires_grad_(True), be.detach().to(dev).requires_grad_(True)
+        out = FF.instance_norm_act(xd, gd, bd, 1e-5, slope)
+        torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-4, atol=1e-5)
+        out.backward(nhwc(gy).to(dev))
+        torch.testing.assert_close(xd.grad.cpu(), nhwc(x.grad), rtol=1e-3, atol=2e-5)
+        torch.testing.assert_close(gd.grad.cpu(), ga.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bd.grad.cpu(), be.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_softmax_rows(dev, FF):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(7)
+    for rows, cols in [(5, 64), (3, 1000), (2, 16384), (4, 37)]:
+        x = torch.randn(rows, cols, generator=g) * 4
+        x[0, 3] = 60.0  # forces a large running-max jump
+        p = torch.softmax(x, -1)
+        dp = torch.randn(rows, cols, generator=g)
+        ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+        xd, dpd = x.to(dev), dp.to(dev)
+        pd = torch.empty_like(xd)
+        lib.softmax_rows_f32(FF._p(xd), FF._p(pd), rows, cols, FF._st())
+        torch.testing.assert_close(pd.cpu(), p, rtol=1e-5, atol=1e-8)
+        lib.softmax_rows_bwd_f32(FF._p(pd), FF._p(dpd), FF._p(dpd), rows, cols, FF._st())
+        torch.testing.assert_close(dpd.cpu(), ds, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,t,d,cs", [(2, 64, 8, (16, 16)), (1, 300, 16, (32,)), (2, 1024, 32, (128, 128))])
+def test_self_attention(dev, FF, n, t, d, cs, monkeypatch):
+    """softmax(q q^T) v, forward and backward, including the multi-chunk path"""
+    monkeypatch.setattr(FF, "ATTN_CHUNK_BYTES", n * t * 4 * 128 * 2)  # force several query chunks
+    g = torch.Generator().manual_seed(8)
+    q = (torch.randn(n, t, d, generator=g) * 0.7).requires_grad_(True)
+    vs = [torch.randn(n, t, c, generator=g).requires_grad_(True) for c in cs]
+    att = torch.softmax(q @ q.transpose(1, 2), -1)
+    outs = [att @ v for v in vs]
+    gos = [torch.randn(o.shape, generator=g) for o in outs]
+    torch.autograd.backward(outs, gos)
+    qd = q.detach().to(dev).requires_grad_(True)
+    vds = [v.detach().to(dev).requires_grad_(True) for v in vs]
+    res = FF.self_attention(qd, vds)
+    for r, o in zip(res, outs):
+        torch.testing.assert_close(r.detach().cpu(), o.detach(), rtol=1e-4, atol=1e-5)
+    torch.autograd.backward(res, [go.to(dev) for go in gos])
+    torch.testing.assert_close(qd.grad.cpu(), q.grad, rtol=1e-3, atol=2e-5)
+    for vd, v in zip(vds, vs):
+        torch.testing.assert_close(vd.grad.cpu(), v.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_small_fused_ops(dev, FF):
+    g = torch.Generator().manual_seed(9)
+    n, h, w, z = 2, 4, 5, 8
+    o_s, o_r = [torch.randn(n, h, w, 2 * z, generator=g).requires_grad_(True) for _ in range(2)]
+    eq, ep = torch.randn(n, h, w, z, generator=g), torch.randn(n, h, w, z, generator=g)
+    zq = o_s[..., :z] + F.softplus(o_s[..., z:]) * eq
+    zp = o_r[..., :z] + F.softplus(o_r[..., z:]) * ep
+    zz = torch.cat([zq, zp], -1)
+    gz = torch.randn(zz.shape, generator=g)
+    zz.backward(gz)
+    sd, rd = o_s.detach().to(dev).requires_grad_(True), o_r.detach().to(dev).requires_grad_(True)
+    out = FF.vae_sample(sd, rd, eq.to(dev), ep.to(dev))
+    torch.testing.assert_close(out.detach().cpu(), zz.detach(), rtol=1e-6, atol=1e-6)
+    out.backward(gz.to(dev))
+    torch.testing.assert_close(sd.grad.cpu(), o_s.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rd.grad.cpu(), o_r.grad, rtol=1e-5, atol=1e-6)
+    # guide blend + cat
+    c = 6
+    ra, rf, sa = [torch.randn(n, h, w, c, generator=g).requires_grad_(True) for _ in range(3)]
+    m = torch.rand(n, h, w, generator=g)
+    ref = torch.cat([(1 - m).unsqueeze(-1) * ra + m.unsqueeze(-1) * rf, sa], -1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    rad, rfd, sad = [t.detach().to(dev).requires_grad_(True) for t in (ra, rf, sa)]
+    out = FF.guide_blend_cat(rad, rfd, sad, m.to(dev))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    out.backward(go.to(dev))
+    for a, b in ((rad, ra), (rfd, rf), (sad, sa)):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-6, atol=1e-6)
+    # gamma * o + x
+    o, x = [torch.randn(n, h, w, c, generator=g).requires_grad_(True) for _ in range(2)]
+    gam = torch.tensor([0.37], requires_grad=True)
+    y = gam * o + x
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    od, xd, gd = o.detach().to(dev).requires_grad_(True), x.detach().to(dev).requires_grad_(True), gam.detach().to(dev).requires_grad_(True)
+    out = FF.scale_add_param(od, gd, xd)
+    torch.testing.assert_close(out.detach().cpu(), y.detach(), rtol=1e-6, atol=1e-6)
+    out.backward(gy.to(dev))
+    torch.testing.assert_close(od.grad.cpu(), o.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gd.grad.cpu(), gam.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_losses_against_golden(dev, FF, golden):
+    fx = golden("picnet_ops.pt")
+    xg = fx["gram"]["x"]
+    n, c, h, w = xg.shape
+    xd = nhwc(xg).to(dev).view(n, h * w, c)
+    torch.testing.assert_close(FF.gram_matrix(xd).cpu(), fx["gram"]["out"], rtol=1e-5, atol=1e-7)
+    from face_mask_inpaint_amd.modules.pluralistic_model import external_function as ef
+
+    for name, fn in (("style_loss", ef.StyleLoss), ("contextual_loss", ef.contextual_loss)):
+        x = fx[name]["x"].to(dev).requires_grad_(True)
+        l = fn(x, fx[name]["y"].to(dev))
+        torch.testing.assert_close(l.detach().cpu(), fx[name]["out"], rtol=1e-5, atol=1e-8)
+        l.backward()
+        torch.testing.assert_close(x.grad.cpu(), fx[name]["gx"], rtol=2e-4, atol=1e-8)
+    gl = ef.GANLoss("lsgan")
+    p = fx["lsgan"]["pred"].to(dev)
+    torch.testing.assert_close(gl(p, True, True).cpu(), fx["lsgan"]["real"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(gl(p, False, True).cpu(), fx["lsgan"]["fake"], rtol=1e-6, atol=1e-7)
+    g = torch.Generator().manual_seed(10)
+    a = torch.randn(2, 3, 17, 19, generator=g, requires_grad=True)
+    b = torch.randn(2, 3, 17, 19, generator=g)
+    for mine, ref in ((FF.l1_loss, F.l1_loss), (FF.mse_loss, F.mse_loss)):
+        l = ref(a, b)
+        (ga,) = torch.autograd.grad(l, a)
+        ad = a.detach().to(dev).requires_grad_(True)
+        lm = mine(ad, b.to(dev))
+        torch.testing.assert_close(lm.detach().cpu(), l.detach(), rtol=1e-6, atol=1e-8)
+        (lm * 3.0).backward()
+        torch.testing.assert_close(ad.grad.cpu(), 3.0 * ga, rtol=1e-6, atol=1e-9)
+
+
+def test_contextual_loss_larger(dev, FF):
+    """28x28 feature map as at full size (784 points), random features"""
+    g = torch.Generator().manual_seed(11)
+    from oracle import picnet_cpu as O  # checker
+
+    x = torch.randn(2, 24, 12, 12, generator=g).abs().requires_grad_(True)
+    y = torch.randn(2, 24, 12, 12, generator=g).abs()
+    l = O.contextual_loss(x, y)
+    l.backward()
+    from face_mask_inpaint_amd.modules.pluralistic_model import external_function as ef
+
+    xd = x.detach().to(dev).requires_grad_(True)
+    lm = ef.contextual_loss(xd, y.to(dev))
+    torch.testing.assert_close(lm.detach().cpu(), l.detach(), rtol=1e-5, atol=1e-7)
+    lm.backward()
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-8)
+
+
+def test_fused_adam_matches_torch(dev):
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    g = torch.Generator().manual_seed(12)
+    shapes = [(7,), (33, 5), (4, 3, 3, 3), (5000,)] * 20  # > 64 tensors: several launches
+    ps = [torch.randn(*s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [p.clone().to(dev).requires_grad_(True) for p in ps]
+    o_ref, o_mine = torch.optim.Adam(ref, lr=1e-2), FusedAdam(mine, lr=1e-2)
+    for step in range(3):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad, m.grad = gr, gr.to(dev)
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,145 @@
+"""GPU: the drop-in nn.Modules (face_mask_inpaint_amd.modules) against the golden vectors produced by the imported
+reference (tests/golden, oracle/gen_golden.py) and, at a larger size, against the CPU oracle.
+Tolerance: 1e-3 relative on fp32 activations end to end (north_star); tighter per block."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+def _load(mod, sd, dev):
+    missing, unexpected = mod.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    # only the aliases of shared convs (model.N.module.* / shortcut.*) may be absent from the de-aliased fixture
+    assert all(".shortcut." in "." + k or ".module." in k for k in missing), missing
+    return mod.to(dev)
+
+
+def _run_block(fx, mod, dev, rtol=1e-4, atol=1e-5, gtol=2e-4):
+    mod = _load(mod, fx["sd0"], dev)
+    xs = [x.to(dev).requires_grad_(True) for x in fx["inputs"]]
+    y = mod(*xs)
+    if isinstance(y, tuple):
+        y = y[0]
+    torch.testing.assert_close(y.detach().cpu(), fx["out"], rtol=rtol, atol=atol)
+    y.backward(fx["gout"].to(dev))
+    for x, g in zip(xs, fx["gin"]):
+        if g.numel():
+            torch.testing.assert_close(x.grad.cpu(), g, rtol=gtol, atol=1e-5)
+    params = dict(mod.named_parameters())
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(params[n].grad.cpu(), g, rtol=gtol, atol=2e-5, msg=lambda m, n=n: f"{n}: {m}")
+    sd1 = mod.state_dict()
+    for k, v in fx["sd1"].items():  # SpectralNorm u/v after one forward
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            torch.testing.assert_close(sd1[k].cpu(), v, rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_blocks_against_reference_golden(dev, golden):
+    from torch import nn
+
+    from face_mask_inpaint_amd.modules.example_guided_att import ExampleGuidedAttention
+    from face_mask_inpaint_amd.modules.pluralistic_model import base_function as bf
+
+    fx = golden("picnet_ops.pt")
+    act = bf.get_nonlinearity_layer("LeakyReLU")
+    inorm = bf.get_norm_layer("instance")
+    _run_block(fx["resblock_none"], bf.ResBlock(8, 16, 8, None, act, "none", True, False), dev)
+    _run_block(fx["resblock_down"], bf.ResBlock(8, 16, 8, None, act, "down", True, False), dev)
+    _run_block(fx["resblock_enc_opt"], bf.ResBlockEncoderOptimized(3, 8, None, act, True, False), dev)
+    _run_block(fx["resblock_dec"], bf.ResBlockDecoder(8, 4, 4, inorm, act, True, False), dev, gtol=1e-3)
+    _run_block(fx["output"], bf.Output(8, 3, 3, None, act, True, False), dev)
+    _run_block(fx["auto_attn"], bf.Auto_Attn(16, None), dev)
+    _run_block(fx["ex_guided_att"], ExampleGuidedAttention(16), dev)
+    _run_block(fx["ex_guided_att_out"], ExampleGuidedAttention(16, 16), dev)
+
+
+def _tiny_models(fx, dev):
+    from face_mask_inpaint_amd.modules.loss import GANOptimizer
+    from face_mask_inpaint_amd.modules.model import ReferenceFill
+    from face_mask_inpaint_amd.modules.pluralistic_model import network
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    cfg = fx["config"]
+    enc = dict(type="pluralistic", ngf=8, z_nc=cfg["enc_z_nc"], img_f=16, layers=5, norm="none", activation="LeakyReLU", L=cfg["enc_L"])
+    dec = dict(ngf=8, z_nc=16, img_f=32, layers=5, norm="instance", activation="LeakyReLU", L=0)
+    G = _load(ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(cfg["out_size"],) * 2), fx["G_sd0"], dev)
+    D = _load(network.define_d(ndf=8, img_f=32, layers=cfg["disc_layers"], norm="none", activation="LeakyReLU", model_type="ResDis"), fx["D_sd0"], dev)
+    optG = FusedAdam([p for p in G.parameters() if p.requires_grad], lr=cfg["lr"])
+    optD = FusedAdam([p for p in D.parameters() if p.requires_grad], lr=cfg["lr"])
+    gopt = GANOptimizer(optD, optG, vgg_width_div=cfg["vgg_div"])
+    gopt.vgg_loss.load_state_dict(fx["V_sd"])
+    return G, D, gopt.to(dev), optG, optD
+
+
+def test_two_training_steps_against_reference_golden(dev, golden):
+    """ReferenceFill.forward + GANOptimizer.__call__ for two consecutive steps: outputs, all five losses, every
+    parameter gradient (captured just before each optimiser step) and the parameters after two Adam updates."""
+    from face_mask_inpaint_amd import functional as FF
+
+    fx = golden("picnet_train_tiny.pt")
+    G, D, gopt, optG, optD = _tiny_models(fx, dev)
+    grads = {"G": [], "D": []}
+
+    def spy(opt, names_params, key):
+        orig = opt.step
+
+        def step(closure=None):
+            grads[key].append({n: p.grad.detach().cpu().clone() for n, p in names_params if p.grad is not None})
+            return orig(closure)
+
+        opt.step = step
+
+    spy(optG, list(G.named_parameters()), "G")
+    spy(optD, list(D.named_parameters()), "D")
+    for step in range(2):
+        s = fx[f"step{step}"]
+        m = FF.binarise_mask(s["mask"].to(dev))
+        assert torch.equal(m.cpu(), (s["mask"] > 0).float())
+        gen = G(s["src"].to(dev), s["ref"].to(dev), src_mask=m, eps=(s["eps_p"].to(dev), s["eps_q"].to(dev)))
+        torch.testing.assert_close(gen.detach().cpu(), s["gen"], rtol=1e-3, atol=1e-5)
+        d_loss, g_loss, perc, sty, cx = gopt(D, s["src"].to(dev), s["gt"].to(dev), s["ref"].to(dev), gen, m)
+        for got, key in ((g_loss, "g_loss"), (d_loss, "d_loss"), (perc, "perc"), (sty, "style"), (cx, "cx")):
+            torch.testing.assert_close(got.detach().cpu(), s[key], rtol=1e-3, atol=1e-9, msg=lambda mm, key=key: f"{key} step {step}: {mm}")
+        for key, ref in (("G", s["G_grads"]), ("D", s["D_grads"])):
+            got = grads[key][step]
+            for n, g in ref.items():
+                assert n in got, f"missing grad {key}.{n}"
+                denom = g.abs().max().clamp_min(1e-12)
+                err = (got[n] - g).abs().max() / denom
+                assert err < 5e-3, f"{key} grad {n} step {step}: rel-to-max error {err:.3e}"
+    for mod, key in ((G, "G_sd2"), (D, "D_sd2")):
+        sd = mod.state_dict()
+        for k, v in fx[key].items():
+            torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-3, atol=2e-5, msg=lambda mm, k=k: f"{key} {k}: {mm}")
+
+
+def test_forward_matches_oracle_at_moderate_size(dev):
+    """real channel widths (ngf 32 / img_f 128 / decoder 256), 64x64 input: 4096-token decoder attention"""
+    from face_mask_inpaint_amd import functional as FF
+    from face_mask_inpaint_amd.modules.model import ReferenceFill
+    from oracle import picnet_cpu as O  # checker
+
+    torch.manual_seed(1)
+    enc = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
+    dec = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
+    G = ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(64, 64))
+    with torch.no_grad():
+        G.decoder.attn1.gamma.fill_(0.5)
+    P = O.prepare_params(G.state_dict())
+    G = G.to(dev)
+    src, ref, gt, mask, eps_p, eps_q = O.synthetic_batch(2, 64, seed=5, feat_hw=8, z_nc=128)
+    with torch.no_grad():
+        want = O.reference_fill_forward(P, src, ref, O.binarise_mask(mask), eps_p, eps_q, out_size=(64, 64))
+        got = G(src.to(dev), ref.to(dev), src_mask=FF.binarise_mask(mask.to(dev)), eps=(eps_p.to(dev), eps_q.to(dev)))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-3, atol=1e-4)
+    # state after the forward (u/v advanced once) must agree too
+    sd = G.state_dict()
+    for k in ("decoder.decoder4.conv2.module.weight_u", "src_encoder.prior.conv1.module.weight_v"):
+        torch.testing.assert_close(sd[k].cpu(), P[k], rtol=1e-4, atol=1e-6)
