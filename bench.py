@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of the PICNet-ref training step (train_reference_fill.py:331-346 +
+GANOptimizer.__call__, loss.py:120-134) at 256x256, bs = 8 per GPU, fp32, synthetic CelebA-HQ-shaped data
+(BASELINE.json configs[1]; configs[3] when launched on 8 GPUs).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline:     achieved TFLOP/s of the fp32-MFMA implicit-GEMM kernel family (csrc/gemm_core.h), measured with
+                events on the launch stream around every launch of one extra (untimed) training step, against
+                the 157.3 TFLOP/s fp32 matrix peak of MI355X;
+  cpu_baseline: the CPU restatement (oracle/picnet_cpu.py, kind "port") timed on this host's cores on a bounded
+                sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+ENC = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
+DEC = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
+DISC = dict(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
+LR = 1e-5  # train_reference_fill.py:22 default
+
+
+def build_models(dev, world):
+    from face_mask_inpaint_amd import distributed as fdist
+    from face_mask_inpaint_amd.modules.loss import GANOptimizer
+    from face_mask_inpaint_amd.modules.model import ReferenceFill
+    from face_mask_inpaint_amd.modules.pluralistic_model import network
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    torch.manual_seed(0)  # identical initial weights on every rank
+    G = ReferenceFill(None, dict(ENC), dict(DEC), use_att=True, out_size=(256, 256)).to(dev)
+    D = network.define_d(**DISC).to(dev)
+    optG = FusedAdam([p for p in G.parameters() if p.requires_grad], lr=LR)
+    optD = FusedAdam([p for p in D.parameters() if p.requires_grad], lr=LR)
+    if world > 1:
+        fdist.broadcast_parameters([G, D])
+        optG, optD = fdist.DataParallelOptimizer(optG), fdist.DataParallelOptimizer(optD)
+    gopt = GANOptimizer(optD, optG).to(dev)
+    if world > 1:
+        fdist.broadcast_parameters([gopt.vgg_loss])
+    return G, D, gopt
+
+
+def synthetic(n, size, seed, dev):
+    """U[0,1) images, int64 binary_map (0 / 255 inside a random lower-face ellipse)"""
+    g = torch.Generator().manual_seed(seed)
+    src, ref, gt = (torch.rand(n, 3, size, size, generator=g) for _ in range(3))
+    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    s = size / 256.0
+    mask = torch.zeros(n, size, size, dtype=torch.long)
+    for i in range(n):
+        r = torch.rand(4, generator=g)
+        cy, cx = (176 + r[0] * 32 - 16) * s, (128 + r[1] * 32 - 16) * s
+        ry, rx = (56 + r[2] * 24 - 12) * s, (80 + r[3] * 24 - 12) * s
+        mask[i][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = 255
+    return [t.to(dev) for t in (src, ref, gt, mask)]
+
+
+def train_step(G, D, gopt, batch):
+    from face_mask_inpaint_amd import functional as FF
+
+    src, ref, gt, mask = batch
+    m = FF.binarise_mask(mask)                      # train_reference_fill.py:340
+    gen = G(src, ref, src_mask=m)                   # :342 (fresh N(0,1) draws for rsample)
+    return gopt(D, src, gt, ref, gen, m)            # :344-346
+
+
+def cpu_baseline(size, seconds_budget=40.0):
+    """the CPU port of the same step on this host's cores: bs = 1 (no batch-coupled op on the path), 1 warm-up + timed steps"""
+    from oracle import picnet_cpu as O  # checker / baseline only -- never imported by the product package
+    from face_mask_inpaint_amd.modules.loss import VGGLoss
+    from face_mask_inpaint_amd.modules.model import ReferenceFill
+    from face_mask_inpaint_amd.modules.pluralistic_model import network
+
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    G = ReferenceFill(None, dict(ENC), dict(DEC), use_att=True, out_size=(256, 256))
+    D = network.define_d(**DISC)
+    PG, PD = O.prepare_params(G.state_dict()), O.prepare_params(D.state_dict())
+    PV = O.prepare_params(VGGLoss().state_dict(), frozen=True)
+    og = torch.optim.Adam(O.unique_trainable(PG), lr=LR)
+    od = torch.optim.Adam(O.unique_trainable(PD), lr=LR)
+    src, ref, gt, mask, eps_p, eps_q = O.synthetic_batch(1, size, seed=1234, feat_hw=size // 8, z_nc=128)
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        O.train_step(PG, PD, PV, og, od, src, gt, ref, mask, eps_p, eps_q, out_size=(size, size))
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget and it >= 1:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = sorted(timed)[len(timed) // 2]
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/picnet_cpu.py train_step at %dx%d, bs=1 (path has no batch-coupled op), 1 warm-up + %d timed steps, median" % (size, size, len(timed))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (weak scaling)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl")  # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from face_mask_inpaint_amd import functional as FF
+
+    G, D, gopt = build_models(dev, world)
+    batch = synthetic(args.batch, args.size, 1234 + rank, dev)
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(G, D, gopt, batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = train_step(G, D, gopt, batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(torch.isfinite(l).item() for l in losses), "non-finite loss"
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        FF.PROFILE = []
+        train_step(G, D, gopt, batch)
+        torch.cuda.synchronize()
+        recs, FF.PROFILE = FF.PROFILE, None
+        tot_ms = sum(s.elapsed_time(e) for _, _, s, e in recs)
+        tot_fl = sum(f for _, f, _, _ in recs)
+        by = {}
+        for tag, f, s, e in recs:
+            a = by.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += f
+            a[1] += s.elapsed_time(e)
+            a[2] += 1
+        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:6]
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_mfma_f32_kernel (fp32 v_mfma_f32_32x32x2 implicit-GEMM family: conv fwd/adjoint/wgrad, attention, gram)",
+                    "launches": len(recs), "kernel_ms_per_step": round(tot_ms, 2), "algorithmic_tflop_per_step": round(tot_fl / 1e12, 3),
+                    "by_call_site": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None, "ms": round(v[1], 2), "launches": v[2]}
+                                     for k, v in top}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.size)
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        out = {"metric": "train images/sec at 256x256 bs=8 per GPU (PICNet-ref train step)", "value": round(imgs / dt, 3),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "train_reference_fill.py PICNet-ref %dx%d fp32, bs=%d per GPU, synthetic CelebA-HQ-shaped batch + random binary_map (BASELINE configs[1]%s)"
+                                      % (args.size, args.size, args.batch, "; configs[3] = bs 64 over 8 GPUs" if world == 8 else ""),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

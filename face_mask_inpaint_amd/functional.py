@@ -22,6 +22,28 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 # scratch budget for one attention score chunk (kept well inside the 256 MB Infinity Cache)
 ATTN_CHUNK_BYTES = 96 * 1024 * 1024
 
+# bench.py sets PROFILE = [] for one untimed step: every launch of the fp32-MFMA GEMM family is then bracketed by
+# events on the launch stream and recorded as (call site, algorithmic flops, start, end).
+PROFILE = None
+
+
+class _prof:
+    def __init__(self, tag, flops):
+        self.tag, self.flops = tag, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.append((self.tag, float(self.flops), self.s, self.e))
+        return False
+
 
 def _L():
     return _lib.lib()
@@ -62,9 +84,10 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------------------------------
-def gemm_raw(a_ptr, b_ptr, c_ptr, M, N, K, sa, sb, sc, batch=1, bs=(0, 0, 0), alpha=1.0, beta=0.0, bias=None):
-    _L().gemm_f32(a_ptr, b_ptr, c_ptr, M, N, K, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], batch, bs[0], bs[1], bs[2],
-                  alpha, beta, _p(bias), _st())
+def gemm_raw(a_ptr, b_ptr, c_ptr, M, N, K, sa, sb, sc, batch=1, bs=(0, 0, 0), alpha=1.0, beta=0.0, bias=None, tag="gemm"):
+    with _prof(tag, 2.0 * M * N * K * batch):
+        _L().gemm_f32(a_ptr, b_ptr, c_ptr, M, N, K, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], batch, bs[0], bs[1], bs[2],
+                      alpha, beta, _p(bias), _st())
 
 
 def eltwise(op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, p0: float = 0.0, out: Optional[torch.Tensor] = None):
@@ -188,7 +211,8 @@ class _Conv2d(torch.autograd.Function):
         k = wf.shape[2]
         d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
+        with _prof("conv_fwd", 2.0 * n * oh * ow * k * c * kh * kw):
+            lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
         ctx.save_for_backward(x, wf, y if act else None)
         ctx.wt, ctx.cfg, ctx.has = wt, (kh, kw, stride, pad, pad_mode, act), (bias is not None, residual is not None)
         return y
@@ -209,17 +233,20 @@ class _Conv2d(torch.autograd.Function):
                 hp, wp = h + 2 * pad, w + 2 * pad
                 d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0)
                 gpad = torch.empty((n, hp, wp, c), device=x.device, dtype=torch.float32)
-                lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gpad), 1, 0, _st())
+                with _prof("conv_dgrad", 2.0 * gy.numel() * c * kh * kw):
+                    lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gpad), 1, 0, _st())
                 gx = torch.empty_like(x)
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
                 d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
                 gx = torch.empty_like(x)
-                lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
+                with _prof("conv_dgrad", 2.0 * gy.numel() * c * kh * kw):
+                    lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
             gwf = torch.zeros_like(wf)
-            lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), 1, 0, _st())
+            with _prof("conv_wgrad", 2.0 * gy.numel() * c * kh * kw):
+                lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
             gb = torch.zeros(k, device=x.device, dtype=torch.float32)
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
@@ -248,7 +275,8 @@ class _ConvTranspose2d(torch.autograd.Function):
         if (oh, ow) != (h, w):
             raise FmiError("unsupported ConvTranspose2d geometry")
         y = torch.empty((n, H, W, cb), device=x.device, dtype=torch.float32)
-        lib.conv2d_dgrad_f32(C.byref(d), _p(x), _p(wt), _p(bias), _p(residual), _p(y), 1, 0, _st())
+        with _prof("convT_fwd", 2.0 * x.numel() * cb * kh * kw):
+            lib.conv2d_dgrad_f32(C.byref(d), _p(x), _p(wt), _p(bias), _p(residual), _p(y), 1, 0, _st())
         ctx.save_for_backward(x, wf)
         ctx.cfg, ctx.has, ctx.HW = (kh, kw, stride, pad), (bias is not None, residual is not None), (H, W)
         return y
@@ -266,10 +294,12 @@ class _ConvTranspose2d(torch.autograd.Function):
         gx = gwf = gb = gres = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
+            with _prof("convT_dgrad", 2.0 * x.numel() * cb * kh * kw):
+                lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
             gwf = torch.zeros_like(wf)
-            lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), 1, 0, _st())
+            with _prof("convT_wgrad", 2.0 * x.numel() * cb * kh * kw):
+                lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
             gb = torch.zeros(cb, device=x.device, dtype=torch.float32)
             lib.bias_grad_f32(_p(gy), gy.numel() // cb, cb, cb, _p(gb), _st())
@@ -574,7 +604,7 @@ def _attn_chunk(n, t):
 
 def _scores(q, n, t, d, q0, qc, buf):
     # S[b, i, j] = q[b, q0+i, :] . q[b, j, :]
-    gemm_raw(_p(q, q0 * d), _p(q), _p(buf), qc, t, d, (d, 1), (1, d), (t, 1), n, (t * d, t * d, qc * t))
+    gemm_raw(_p(q, q0 * d), _p(q), _p(buf), qc, t, d, (d, 1), (1, d), (t, 1), n, (t * d, t * d, qc * t), tag="attn_qk")
     _L().softmax_rows_f32(_p(buf), _p(buf), n * qc, t, _st())
 
 
@@ -591,7 +621,7 @@ class _SelfAttention(torch.autograd.Function):
             _scores(q, n, t, d, q0, qc, buf)
             for v, o in zip(vs, outs):
                 c = v.shape[2]
-                gemm_raw(_p(buf), _p(v), _p(o, q0 * c), qc, c, t, (t, 1), (c, 1), (c, 1), n, (qc * t, t * c, t * c))
+                gemm_raw(_p(buf), _p(v), _p(o, q0 * c), qc, c, t, (t, 1), (c, 1), (c, 1), n, (qc * t, t * c, t * c), tag="attn_pv")
         ctx.save_for_backward(q, *vs)
         return tuple(outs)
 
@@ -615,16 +645,16 @@ class _SelfAttention(torch.autograd.Function):
                     continue
                 c = v.shape[2]
                 # dV += P^T dO_chunk
-                gemm_raw(_p(P), _p(g, q0 * c), _p(gv), t, c, qc, (1, t), (c, 1), (c, 1), n, (qc * t, t * c, t * c), 1.0, 1.0)
+                gemm_raw(_p(P), _p(g, q0 * c), _p(gv), t, c, qc, (1, t), (c, 1), (c, 1), n, (qc * t, t * c, t * c), 1.0, 1.0, tag="attn_bwd_dv")
                 # dP (+)= dO_chunk V^T
-                gemm_raw(_p(g, q0 * c), _p(v), _p(dP), qc, t, c, (c, 1), (1, c), (t, 1), n, (t * c, t * c, qc * t), 1.0, 0.0 if first else 1.0)
+                gemm_raw(_p(g, q0 * c), _p(v), _p(dP), qc, t, c, (c, 1), (1, c), (t, 1), n, (t * c, t * c, qc * t), 1.0, 0.0 if first else 1.0, tag="attn_bwd_dp")
                 first = False
             if first:
                 continue
             _L().softmax_rows_bwd_f32(_p(P), _p(dP), _p(dP), n * qc, t, _st())
             # query side: dQ[chunk] += dS Q ; key side: dQ += dS^T Q[chunk]
-            gemm_raw(_p(dP), _p(q), _p(gq, q0 * d), qc, d, t, (t, 1), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0)
-            gemm_raw(_p(dP), _p(q, q0 * d), _p(gq), t, d, qc, (1, t), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0)
+            gemm_raw(_p(dP), _p(q), _p(gq, q0 * d), qc, d, t, (t, 1), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dq")
+            gemm_raw(_p(dP), _p(q, q0 * d), _p(gq), t, d, qc, (1, t), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dk")
         return (gq,) + tuple(gvs)
 
 

@@ -21,16 +21,16 @@ def _load(mod, sd, dev):
     return mod.to(dev)
 
 
-def _run_block(fx, mod, dev, rtol=1e-4, atol=1e-5, gtol=2e-4):
+def _run_block(fx, mod, dev, rtol=1e-4, atol=1e-5, gtol=2e-4, const_inputs=()):
     mod = _load(mod, fx["sd0"], dev)
-    xs = [x.to(dev).requires_grad_(True) for x in fx["inputs"]]
+    xs = [x.to(dev).requires_grad_(i not in const_inputs) for i, x in enumerate(fx["inputs"])]
     y = mod(*xs)
     if isinstance(y, tuple):
         y = y[0]
     torch.testing.assert_close(y.detach().cpu(), fx["out"], rtol=rtol, atol=atol)
     y.backward(fx["gout"].to(dev))
-    for x, g in zip(xs, fx["gin"]):
-        if g.numel():
+    for i, (x, g) in enumerate(zip(xs, fx["gin"])):
+        if g.numel() and i not in const_inputs:
             torch.testing.assert_close(x.grad.cpu(), g, rtol=gtol, atol=1e-5)
     params = dict(mod.named_parameters())
     for n, g in fx["gparams"].items():
@@ -56,8 +56,8 @@ def test_blocks_against_reference_golden(dev, golden):
     _run_block(fx["resblock_dec"], bf.ResBlockDecoder(8, 4, 4, inorm, act, True, False), dev, gtol=1e-3)
     _run_block(fx["output"], bf.Output(8, 3, 3, None, act, True, False), dev)
     _run_block(fx["auto_attn"], bf.Auto_Attn(16, None), dev)
-    _run_block(fx["ex_guided_att"], ExampleGuidedAttention(16), dev)
-    _run_block(fx["ex_guided_att_out"], ExampleGuidedAttention(16, 16), dev)
+    _run_block(fx["ex_guided_att"], ExampleGuidedAttention(16), dev, const_inputs=(0,))  # the mask never carries a gradient
+    _run_block(fx["ex_guided_att_out"], ExampleGuidedAttention(16, 16), dev, const_inputs=(0,))
 
 
 def _tiny_models(fx, dev):
@@ -111,9 +111,11 @@ def test_two_training_steps_against_reference_golden(dev, golden):
             got = grads[key][step]
             for n, g in ref.items():
                 assert n in got, f"missing grad {key}.{n}"
-                denom = g.abs().max().clamp_min(1e-12)
-                err = (got[n] - g).abs().max() / denom
-                assert err < 5e-3, f"{key} grad {n} step {step}: rel-to-max error {err:.3e}"
+                # relative to the tensor's largest entry; the 1e-7 floor covers gradients that are analytically zero
+                # (a conv bias in front of InstanceNorm) and hold only rounding noise on both sides
+                err = (got[n] - g).abs().max()
+                lim = 5e-3 * g.abs().max() + 1e-7
+                assert err <= lim, f"{key} grad {n} step {step}: max error {err:.3e} > {lim:.3e}"
     for mod, key in ((G, "G_sd2"), (D, "D_sd2")):
         sd = mod.state_dict()
         for k, v in fx[key].items():
