@@ -3,9 +3,44 @@
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+#ifndef FMI_HOST_EMU
+// C = beta*C + bias[n] over a strided [batch][M][N] region: prologue of the split-K path
+__global__ void __launch_bounds__(256) c_prep_kernel(float* __restrict__ C, int M, int N, int64_t sc_m, int64_t sc_n,
+                                                     int64_t sc_b, float beta, const float* __restrict__ bias, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i % N);
+    const int64_t r = i / N;
+    const int m = (int)(r % M);
+    const int64_t b = r / M;
+    float* q = C + b * sc_b + (int64_t)m * sc_m + (int64_t)n * sc_n;
+    float v = beta == 0.f ? 0.f : beta * *q;
+    if (bias) v += bias[n];
+    *q = v;
+  }
+}
+#endif
+
 template <class LA, class LB>
 static int run(const LA& la, const LB& lb, float* C, int M, int N, int K, int64_t sc_m, int64_t sc_n, int64_t sc_b,
                int batch, float alpha, float beta, const float* bias, hipStream_t st) {
+#ifndef FMI_HOST_EMU
+  // Skinny outputs with a long reduction (attention P.V: 128 x 256 outputs, K = 16384) would occupy a handful of
+  // CUs: split K over workgroups and let the partial tiles meet through fp32 atomics.
+  const int64_t tiles = ceil_div64(M, M <= 64 ? 64 : 128) * ceil_div64(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128)) * batch;
+  if (tiles < 192 && K >= 2048) {
+    int64_t ks = 768 / tiles;
+    if (ks > K / 512) ks = K / 512;
+    if (ks * batch > 65535) ks = 65535 / batch;
+    if (ks >= 2) {
+      if (beta != 1.f || bias) {
+        const int64_t total = (int64_t)batch * M * N;
+        hipLaunchKernelGGL(c_prep_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, st, C, M, N, sc_m, sc_n, sc_b, beta, bias, total);
+      }
+      DenseEp ep{C, nullptr, sc_m, sc_n, sc_b, alpha, 0.f, 1};
+      return launch_gemm(la, lb, ep, M, N, K, batch, (int)ks, st);
+    }
+  }
+#endif
   DenseEp ep{C, bias, sc_m, sc_n, sc_b, alpha, beta, 0};
   return launch_gemm(la, lb, ep, M, N, K, batch, 1, st);
 }

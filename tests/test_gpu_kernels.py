@@ -56,6 +56,20 @@ def test_gemm(dev, FF, ta, tb, m, n, k, bsz):
     torch.testing.assert_close(c.cpu().double(), ref, rtol=1e-5, atol=1e-4)
 
 
+def test_gemm_split_k_skinny(dev, FF):
+    """skinny output + long reduction takes the split-K / fp32-atomic path (attention P.V and dS.K shapes)"""
+    g = torch.Generator().manual_seed(77)
+    for (m, n, k, bsz, beta) in [(128, 256, 4096, 2, 0.0), (100, 64, 8192, 1, 1.0), (128, 40, 2048, 3, 0.5)]:
+        a = torch.randn(bsz, m, k, generator=g) / k ** 0.5
+        b = torch.randn(bsz, k, n, generator=g)
+        c0 = torch.randn(bsz, m, n, generator=g)
+        bias = torch.randn(n, generator=g)
+        ad, bd, c, biasd = a.to(dev), b.to(dev), c0.clone().to(dev), bias.to(dev)
+        FF.gemm_raw(FF._p(ad), FF._p(bd), FF._p(c), m, n, k, (k, 1), (n, 1), (n, 1), bsz, (m * k, k * n, m * n), 2.0, beta, biasd)
+        ref = 2.0 * (a.double() @ b.double()) + bias.double() + beta * c0.double()
+        torch.testing.assert_close(c.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+
+
 def test_gemm_mfma_layout_asymmetric(dev, FF):
     """A = I against an asymmetric integer B catches swapped row/column fragment maps exactly."""
     n = 96
