@@ -78,7 +78,24 @@ def train_step(G, D, gopt, batch):
     return gopt(D, src, gt, ref, gen, m)            # :344-346
 
 
-def cpu_baseline(size, seconds_budget=40.0):
+def host_cores() -> int:
+    """cores this process may actually use: min(affinity, cgroup cpu quota) -- the GPU box shows 256 logical CPUs
+    but grants a 16-CPU quota, and 256 torch threads on 16 CPUs never finish"""
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def cpu_baseline(size, seconds_budget=30.0):
     """the CPU port of the same step on this host's cores: bs = 1 (no batch-coupled op on the path), 1 warm-up + timed steps"""
     from oracle import picnet_cpu as O  # checker / baseline only -- never imported by the product package
     from face_mask_inpaint_amd.modules.loss import VGGLoss
@@ -86,11 +103,7 @@ def cpu_baseline(size, seconds_budget=40.0):
     from face_mask_inpaint_amd.modules.pluralistic_model import network
 
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     G = ReferenceFill(None, dict(ENC), dict(DEC), use_att=True, out_size=(256, 256))
     D = network.define_d(**DISC)
@@ -101,7 +114,7 @@ def cpu_baseline(size, seconds_budget=40.0):
     src, ref, gt, mask, eps_p, eps_q = O.synthetic_batch(1, size, seed=1234, feat_hw=size // 8, z_nc=128)
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(6):
         t0 = time.time()
         O.train_step(PG, PD, PV, og, od, src, gt, ref, mask, eps_p, eps_q, out_size=(size, size))
         times.append(time.time() - t0)
@@ -122,6 +135,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-dump", default=None, help="write the per-shape launch table of the profiled step here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,12 +186,21 @@ def main():
         recs, FF.PROFILE = FF.PROFILE, None
         tot_ms = sum(s.elapsed_time(e) for _, _, s, e in recs)
         tot_fl = sum(f for _, f, _, _ in recs)
-        by = {}
+        by, detail = {}, {}
         for tag, f, s, e in recs:
+            d = detail.setdefault(tag, [0.0, 0.0, 0])
+            d[0] += f
+            d[1] += s.elapsed_time(e)
+            d[2] += 1
+            tag = tag.split("|")[0]
             a = by.setdefault(tag, [0.0, 0.0, 0])
             a[0] += f
             a[1] += s.elapsed_time(e)
             a[2] += 1
+        if args.profile_dump:
+            with open(args.profile_dump, "w") as fh:
+                for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1]):
+                    fh.write("%9.3f ms %4d launches %7.1f TFLOP/s  %s\n" % (v[1], v[2], v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0, k))
         top = sorted(by.items(), key=lambda kv: -kv[1][1])[:6]
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

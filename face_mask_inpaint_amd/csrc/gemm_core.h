@@ -448,17 +448,22 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
     if (more) gload(k0 + BK);
     const float* a = As + buf * BK * LDA + wm + l31;
     const float* b = Bs + buf * BK * LDB + wn + l31;
+    // all fragments of the 16-deep tile first (counted lgkmcnt waits let the MFMAs start as they arrive),
+    // then 8 x TM x TN back-to-back MFMAs: the LDS latency is exposed once per tile, not once per k-pair
+    float fa[BK / 2][T::TM], fb[BK / 2][T::TN];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float fa[T::TM], fb[T::TN];
+    for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
-      for (int i = 0; i < T::TM; ++i) fa[i] = a[(kk + lh) * LDA + i * 32];
+      for (int i = 0; i < T::TM; ++i) fa[kk][i] = a[(2 * kk + lh) * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) fb[j] = b[(kk + lh) * LDB + j * 32];
+      for (int j = 0; j < T::TN; ++j) fb[kk][j] = b[(2 * kk + lh) * LDB + j * 32];
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();

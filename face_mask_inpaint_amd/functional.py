@@ -85,7 +85,7 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
 # raw wrappers (no autograd)
 # ---------------------------------------------------------------------------------------------------
 def gemm_raw(a_ptr, b_ptr, c_ptr, M, N, K, sa, sb, sc, batch=1, bs=(0, 0, 0), alpha=1.0, beta=0.0, bias=None, tag="gemm"):
-    with _prof(tag, 2.0 * M * N * K * batch):
+    with _prof(f"{tag}|{M}x{N}x{K} b{batch}", 2.0 * M * N * K * batch):
         _L().gemm_f32(a_ptr, b_ptr, c_ptr, M, N, K, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], batch, bs[0], bs[1], bs[2],
                       alpha, beta, _p(bias), _st())
 
@@ -211,7 +211,7 @@ class _Conv2d(torch.autograd.Function):
         k = wf.shape[2]
         d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        with _prof("conv_fwd", 2.0 * n * oh * ow * k * c * kh * kw):
+        with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * n * oh * ow * k * c * kh * kw):
             lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
         ctx.save_for_backward(x, wf, y if act else None)
         ctx.wt, ctx.cfg, ctx.has = wt, (kh, kw, stride, pad, pad_mode, act), (bias is not None, residual is not None)
@@ -233,19 +233,19 @@ class _Conv2d(torch.autograd.Function):
                 hp, wp = h + 2 * pad, w + 2 * pad
                 d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0)
                 gpad = torch.empty((n, hp, wp, c), device=x.device, dtype=torch.float32)
-                with _prof("conv_dgrad", 2.0 * gy.numel() * c * kh * kw):
+                with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gpad), 1, 0, _st())
                 gx = torch.empty_like(x)
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
                 d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
                 gx = torch.empty_like(x)
-                with _prof("conv_dgrad", 2.0 * gy.numel() * c * kh * kw):
+                with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
             gwf = torch.zeros_like(wf)
-            with _prof("conv_wgrad", 2.0 * gy.numel() * c * kh * kw):
+            with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
             gb = torch.zeros(k, device=x.device, dtype=torch.float32)
@@ -275,7 +275,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if (oh, ow) != (h, w):
             raise FmiError("unsupported ConvTranspose2d geometry")
         y = torch.empty((n, H, W, cb), device=x.device, dtype=torch.float32)
-        with _prof("convT_fwd", 2.0 * x.numel() * cb * kh * kw):
+        with _prof(f"convT_fwd|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
             lib.conv2d_dgrad_f32(C.byref(d), _p(x), _p(wt), _p(bias), _p(residual), _p(y), 1, 0, _st())
         ctx.save_for_backward(x, wf)
         ctx.cfg, ctx.has, ctx.HW = (kh, kw, stride, pad), (bias is not None, residual is not None), (H, W)
@@ -294,11 +294,11 @@ class _ConvTranspose2d(torch.autograd.Function):
         gx = gwf = gb = gres = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            with _prof("convT_dgrad", 2.0 * x.numel() * cb * kh * kw):
+            with _prof(f"convT_dgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
             gwf = torch.zeros_like(wf)
-            with _prof("convT_wgrad", 2.0 * x.numel() * cb * kh * kw):
+            with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
             gb = torch.zeros(cb, device=x.device, dtype=torch.float32)
