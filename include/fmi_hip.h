@@ -253,6 +253,8 @@ int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int majo
  * bias / ref may be NULL. */
 int fmi_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* out, int64_t n,
                            int step_b, int size_b, int act, int grad, float alpha, float scale, void* stream);
+/* dbias[c] += sum_{n,hw} g[n][c][hw] for NCHW g (grad_bias of FusedLeakyReLU, op/fused_act.py:29-36); caller zeroes dbias */
+int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream);
 /* NHWC variant used by the product's StyledConv: y = lrelu(x + bias[c] + nw[0]*noise[p]) * scale */
 int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise, const float* nw, float* y,
                            int64_t pixels, int C, float alpha, float scale, void* stream);

@@ -119,3 +119,45 @@ def _gen_losses(PD, PV, s, gen, mask, cfg):
     sty = O.vgg_loss(PV, "", gen * (1 - mask).unsqueeze(1), s["src"], "style") * O.LAMBDA_STYLE
     cx = O.vgg_loss(PV, "", gen * mask.unsqueeze(1), s["ref"] * mask.unsqueeze(1), "contextual") * O.LAMBDA_CX
     return g + perc + sty + cx, perc, sty, cx
+
+
+# ---- StyleGAN2 decoder pieces ------------------------------------------------------------------------------
+def test_stylegan2_native_ops_oracle(golden):
+    """C restatement of upfirdn2d / fused_bias_act against the reference's own upfirdn2d_native outputs"""
+    from oracle import stylegan2_cpu as S
+
+    fx = golden("stylegan2_ops.pt")
+    for case in fx["upfirdn2d"]:
+        px0, px1, py0, py1 = case["pad"]
+        got = S.upfirdn2d_planes(case["x"], case["k"], case["up"], case["up"], case["down"], case["down"], px0, px1, py0, py1)
+        torch.testing.assert_close(got, case["out"], rtol=1e-5, atol=1e-6)
+        if px0 == py0 and px1 == py1:
+            got_t = S.upfirdn2d_t(case["x"].unsqueeze(0), case["k"], case["up"], case["down"], (px0, px1))[0]
+            torch.testing.assert_close(got_t, case["out"], rtol=1e-5, atol=1e-6)
+    f = fx["fused_lrelu"]
+    torch.testing.assert_close(S.fused_leaky_relu(f["x"], f["b"]), f["out"], rtol=1e-6, atol=1e-7)
+    m = torch.randint(-5, 300, (3, 7, 9))
+    assert torch.equal(S.mask_binarise(m), (m > 0).float())
+
+
+def test_stylegan2_blocks_oracle(golden):
+    from oracle import stylegan2_cpu as S
+
+    fx = golden("stylegan2_ops.pt")
+    for name, up, demod in (("modconv", False, True), ("modconv_up", True, True), ("modconv_rgb", False, False)):
+        f = fx[name]
+        P = {"m." + k: v.clone().requires_grad_(True) for k, v in f["sd"].items() if v.dtype.is_floating_point}
+        x, s = f["x"].clone().requires_grad_(True), f["style"].clone().requires_grad_(True)
+        y = S.modulated_conv(P, "m", x, s, demodulate=demod, upsample=up)
+        torch.testing.assert_close(y, f["out"], rtol=1e-4, atol=1e-5)
+        y.backward(f["gout"])
+        torch.testing.assert_close(x.grad, f["gx"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(s.grad, f["gstyle"], rtol=1e-4, atol=1e-5)
+        for n, g in f["gparams"].items():
+            torch.testing.assert_close(P["m." + n].grad, g, rtol=1e-4, atol=1e-5)
+    f = fx["styledconv_up"]
+    P = {"m." + k: v.clone() for k, v in f["sd"].items() if v.dtype.is_floating_point}
+    torch.testing.assert_close(S.styled_conv(P, "m", f["x"], f["style"], f["noise"], upsample=True), f["out"], rtol=1e-4, atol=1e-5)
+    f = fx["torgb"]
+    P = {"m." + k: v.clone() for k, v in f["sd"].items() if v.dtype.is_floating_point}
+    torch.testing.assert_close(S.to_rgb(P, "m", f["x"], f["style"], f["skip"]), f["out"], rtol=1e-4, atol=1e-5)
