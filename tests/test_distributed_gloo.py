@@ -1,0 +1,72 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient exchange used by bench.py for N > 1
+(face_mask_inpaint_amd/distributed.py).  Two ranks with different data must end up with identical parameters,
+equal to one process that saw both shards (mean-reduced losses), including a parameter that never receives a
+gradient (Auto_Attn.alpha-like) and bucket boundaries that split the gradient list."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    m.unused = torch.nn.Parameter(torch.zeros(1))  # never receives a gradient
+    return m
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from face_mask_inpaint_amd import distributed as fd
+
+    m = _model()
+    if rank == 1:  # start from different weights: broadcast must fix that
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(1.0)
+    fd.broadcast_parameters([m])
+    opt = fd.DataParallelOptimizer(torch.optim.Adam(m.parameters(), lr=1e-2), bucket_bytes=256)  # forces several buckets
+    x, y = _data(rank)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(m(x), y).backward()
+        opt.step()
+    assert fd.allreduce_gradients(m.parameters(), bucket_bytes=256) >= 2
+    torch.save({k: v.clone() for k, v in m.state_dict().items()}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange(tmp_path):
+    port, out = _free_port(), str(tmp_path / "sd")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # single process on the union of the shards: mean of the two per-shard mean losses
+    m = _model()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    (x0, y0), (x1, y1) = _data(0), _data(1)
+    for _ in range(3):
+        opt.zero_grad()
+        (0.5 * (torch.nn.functional.mse_loss(m(x0), y0) + torch.nn.functional.mse_loss(m(x1), y1))).backward()
+        opt.step()
+    for k, v in m.state_dict().items():
+        torch.testing.assert_close(a[k], v, rtol=1e-5, atol=1e-6)
+    assert float(a["unused"]) == 0.0
