@@ -44,7 +44,7 @@ SIGNATURES = {
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_weight_prepare_f32": [vp, i32, vp],
-    "fmi_weight_grad_f32": [vp, i32, vp],
+    "fmi_weight_grad_f32": [vp, i32, vp, vp],
     "fmi_softmax_rows_f32": [vp, vp, i64, i32, vp],
     "fmi_softmax_rows_bwd_f32": [vp, vp, vp, i64, i32, vp],
     "fmi_eltwise_f32": [i32, vp, vp, vp, i64, f32, vp],

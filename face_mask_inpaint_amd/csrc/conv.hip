@@ -113,7 +113,35 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
 #ifndef FMI_HOST_EMU
 // ---------------------------------------------------------------------------------------------
 // dbias[k] += sum_rows g[row*cstride + k]
+// vector form (K % 4 == 0, K/4 divides 256): the tensor is streamed as float4, 256 threads cover 256/(K/4) rows per
+// pass with fully coalesced 16-byte loads; threads owning the same 4 channels are combined through LDS.
 // ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bias_grad_vec_kernel(const float* __restrict__ g, int64_t rows, int K4,
+                                                            float* __restrict__ dbias, int64_t rows_per_block) {
+  __shared__ float4 part[256];
+  const int cg = threadIdx.x % K4, rl = threadIdx.x / K4, RL = 256 / K4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    const float4 v = reinterpret_cast<const float4*>(g)[r * K4 + cg];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < K4) {
+    float4 t = part[threadIdx.x];
+    for (int l = 1; l < RL; ++l) {
+      const float4 v = part[l * K4 + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    atomicAdd(dbias + 4 * threadIdx.x + 0, t.x);
+    atomicAdd(dbias + 4 * threadIdx.x + 1, t.y);
+    atomicAdd(dbias + 4 * threadIdx.x + 2, t.z);
+    atomicAdd(dbias + 4 * threadIdx.x + 3, t.w);
+  }
+}
 __global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ g, int64_t rows, int K, int cstride,
                                                         float* __restrict__ dbias, int64_t rows_per_block) {
   __shared__ float part[4][64];
@@ -139,8 +167,11 @@ extern "C" int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstrid
   if (blocks > 2048) blocks = 2048;
   const int64_t rpb = ceil_div64(rows, blocks);
   blocks = ceil_div64(rows, rpb);
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K, cstride,
-                     dbias, rpb);
+  const int K4 = K / 4;
+  if (K % 4 == 0 && cstride == K && K4 <= 256 && (K4 & (K4 - 1)) == 0 && (((uintptr_t)g) & 15) == 0)
+    hipLaunchKernelGGL(bias_grad_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K4, dbias, rpb);
+  else
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K, cstride, dbias, rpb);
   return fmi_launch_status();
 }
 

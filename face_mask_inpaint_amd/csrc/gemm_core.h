@@ -508,12 +508,21 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
     hipLaunchKernelGGL((gemm_mfma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
                        0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                                  \
   } while (0)
-  if (M <= 32 && N > 64) FMI_LAUNCH(Tile32x128);
-  else if (N <= 32) FMI_LAUNCH(Tile128x32);
-  else if (M <= 64 && N <= 64) FMI_LAUNCH(Tile64x64);
-  else if (M <= 64) FMI_LAUNCH(Tile64x128);
-  else if (N <= 64) FMI_LAUNCH(Tile128x64);
-  else FMI_LAUNCH(Tile128x128);
+  // largest tile that still gives ~1.5 workgroups per CU; small problems trade operand reuse for occupancy
+  const int64_t zs = gy;
+  auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn) * zs; };
+  const int64_t want = 384;
+  if (N <= 32) {
+    FMI_LAUNCH(Tile128x32);
+  } else if (N <= 64) {
+    if (M > 64 && wgs(128, 64) >= want) FMI_LAUNCH(Tile128x64);
+    else FMI_LAUNCH(Tile64x64);
+  } else {
+    if (M > 64 && wgs(128, 128) >= want) FMI_LAUNCH(Tile128x128);
+    else if (M > 32 && wgs(64, 128) >= want) FMI_LAUNCH(Tile64x128);
+    else if (M > 64 && wgs(32, 128) < 256) FMI_LAUNCH(Tile64x128);
+    else FMI_LAUNCH(Tile32x128);
+  }
 #undef FMI_LAUNCH
   return fmi_launch_status();
 }

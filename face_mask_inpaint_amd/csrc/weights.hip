@@ -6,79 +6,95 @@
 // bandwidth, optimisations: they replace ~6 tiny ATen kernels per conv per forward.
 #include "common.h"
 
-#define SN_MAX_WIDTH 8192  // floats of v kept in LDS
-#define SN_MAX_ROWS 1024
-
+#define SN_MAX_ROWS 4096
 #define ENTRY_CHUNK 32
 struct PrepArgs { fmi_weight_entry e[ENTRY_CHUNK]; };
 struct GradArgs { fmi_weight_grad_entry e[ENTRY_CHUNK]; };
 struct AdamArgs { fmi_adam_entry e[ENTRY_CHUNK * 2]; };
 
-__global__ void __launch_bounds__(256) weight_prepare_kernel(const PrepArgs args) {
-  const fmi_weight_entry* entries = args.e;
-  __shared__ float sv[SN_MAX_WIDTH];
+// Every stage is a 2-D grid: blockIdx.y = weight tensor (<= 32 per launch), blockIdx.x = slice of that tensor
+// (surplus slices exit).  Five small, fully parallel launches replace one workgroup streaming a 2.4 MB weight
+// four times (1.4 ms per launch in the first version of this file).
+
+// stage 1: v_raw[j] = sum_r W[r][j] u[r]   (thread per column, coalesced along the row; written into v)
+__global__ void __launch_bounds__(256) wp_wtu_kernel(const PrepArgs args) {
   __shared__ float su[SN_MAX_ROWS];
+  const fmi_weight_entry e = args.e[blockIdx.y];
+  if (!e.u) return;
+  const int width = e.C * e.taps, j0 = blockIdx.x * 256;
+  if (j0 >= width) return;
+  for (int i = threadIdx.x; i < e.rows; i += 256) su[i] = e.u[i];
+  __syncthreads();
+  const int j = j0 + threadIdx.x;
+  if (j >= width) return;
+  float s = 0.f;
+  for (int r = 0; r < e.rows; ++r) s += e.w[(int64_t)r * width + j] * su[r];
+  e.v[j] = s;
+}
+// stage 2: v = v_raw / (||v_raw|| + 1e-12)
+__global__ void __launch_bounds__(256) wp_vnorm_kernel(const PrepArgs args) {
   __shared__ float red[4];
-  const fmi_weight_entry e = entries[blockIdx.x];
+  const fmi_weight_entry e = args.e[blockIdx.x];
+  if (!e.u) return;
+  const int width = e.C * e.taps;
+  float n = 0.f;
+  for (int j = threadIdx.x; j < width; j += 256) n += e.v[j] * e.v[j];
+  n = sqrtf(block_sum_256(n, red));
+  const float d = n + 1e-12f;
+  for (int j = threadIdx.x; j < width; j += 256) e.v[j] = e.v[j] / d;
+}
+// stage 3: t[r] = W[r,:] . v  (one wave per row; written into u, whose old value is no longer needed)
+__global__ void __launch_bounds__(256) wp_wv_kernel(const PrepArgs args) {
+  const fmi_weight_entry e = args.e[blockIdx.y];
+  if (!e.u) return;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= e.rows) return;
+  const int width = e.C * e.taps;
+  float s = 0.f;
+  for (int j = lane; j < width; j += 64) s += e.w[(int64_t)r * width + j] * e.v[j];
+  s = wave_sum(s);
+  if (lane == 0) e.u[r] = s;
+}
+// stage 4: u = t / (||t|| + 1e-12); sigma = u . t
+__global__ void __launch_bounds__(256) wp_unorm_kernel(const PrepArgs args) {
+  __shared__ float red[4];
+  const fmi_weight_entry e = args.e[blockIdx.x];
+  if (!e.u) return;
+  float n = 0.f;
+  for (int i = threadIdx.x; i < e.rows; i += 256) n += e.u[i] * e.u[i];
+  n = sqrtf(block_sum_256(n, red));
+  const float d = n + 1e-12f;
+  float sg = 0.f;
+  for (int i = threadIdx.x; i < e.rows; i += 256) {
+    const float t = e.u[i], un = t / d;
+    e.u[i] = un;
+    sg += un * t;
+  }
+  sg = block_sum_256(sg, red);
+  if (threadIdx.x == 0) e.sigma[0] = sg;
+}
+// stage 5: packed copies of W / sigma: wf[tap][c][row] (row fastest) and wt[tap][row][c] (c fastest)
+#define PACK_PER_BLOCK 2048
+__global__ void __launch_bounds__(256) wp_pack_kernel(const PrepArgs args) {
+  const fmi_weight_entry e = args.e[blockIdx.y];
   const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
-  const float* __restrict__ W = e.w;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  float sigma = 1.f;
-  if (e.u) {
-    for (int i = tid; i < rows; i += 256) su[i] = e.u[i];
-    __syncthreads();
-    // v = normalize(W^T u): thread per column, coalesced along the row
-    float nv = 0.f;
-    for (int j = tid; j < width; j += 256) {
-      float s = 0.f;
-      for (int i = 0; i < rows; ++i) s += W[(int64_t)i * width + j] * su[i];
-      sv[j] = s;
-      nv += s * s;
+  const int64_t total = (int64_t)rows * width, base = (int64_t)blockIdx.x * PACK_PER_BLOCK;
+  if (base >= total) return;
+  const float sigma = e.u ? e.sigma[0] : 1.f;
+  for (int64_t o = base + threadIdx.x; o < base + PACK_PER_BLOCK && o < total; o += 256) {
+    {
+      const int r = (int)(o % rows);
+      const int64_t q = o / rows;
+      const int c = (int)(q % C), tap = (int)(q / C);
+      float v = e.w[(int64_t)r * width + c * taps + tap];
+      if (e.u) v = v / sigma;
+      e.wf[o] = v;
     }
-    nv = sqrtf(block_sum_256(nv, red));
-    const float iv = nv + 1e-12f;
-    for (int j = tid; j < width; j += 256) {
-      const float v = sv[j] / iv;
-      sv[j] = v;
-      e.v[j] = v;
-    }
-    __syncthreads();
-    // t = W v : one wave per row, lanes stride the row
-    float nu = 0.f;
-    for (int i = wid; i < rows; i += 4) {
-      float s = 0.f;
-      for (int j = lane; j < width; j += 64) s += W[(int64_t)i * width + j] * sv[j];
-      s = wave_sum(s);
-      if (lane == 0) su[i] = s;
-      nu += (lane == 0) ? s * s : 0.f;
-    }
-    nu = sqrtf(block_sum_256(nu, red));  // also orders the su[] writes
-    const float iu = nu + 1e-12f;
-    float sg = 0.f;
-    for (int i = tid; i < rows; i += 256) {
-      const float t = su[i], un = t / iu;
-      e.u[i] = un;
-      sg += un * t;  // sigma = u . (W v)
-    }
-    sigma = block_sum_256(sg, red);
-    if (tid == 0 && e.sigma) e.sigma[0] = sigma;
-  }
-  // packed copies of W / sigma: wf[tap][c][row] (row fastest) and wt[tap][row][c] (c fastest)
-  const int64_t total = (int64_t)rows * width;
-  for (int64_t o = tid; o < total; o += 256) {
-    const int r = (int)(o % rows);
-    const int64_t q = o / rows;
-    const int c = (int)(q % C), tap = (int)(q / C);
-    float v = W[(int64_t)r * width + c * taps + tap];
-    if (e.u) v = v / sigma;
-    e.wf[o] = v;
-  }
-  if (e.wt) {
-    for (int64_t o = tid; o < total; o += 256) {
+    if (e.wt) {
       const int c = (int)(o % C);
       const int64_t q = o / C;
       const int r = (int)(q % rows), tap = (int)(q / rows);
-      float v = W[(int64_t)r * width + c * taps + tap];
+      float v = e.w[(int64_t)r * width + c * taps + tap];
       if (e.u) v = v / sigma;
       e.wt[o] = v;
     }
@@ -91,39 +107,63 @@ extern "C" int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count
     const fmi_weight_entry& e = entries[i];
     if (!e.w || !e.wf || e.rows <= 0 || e.C <= 0 || e.taps <= 0) return FMI_ERR_BAD_ARG;
     if (e.u && (!e.v || !e.sigma)) return FMI_ERR_BAD_ARG;
-    if (e.u && (e.rows > SN_MAX_ROWS || e.C * e.taps > SN_MAX_WIDTH)) return FMI_ERR_UNSUPPORTED;
+    if (e.u && e.rows > SN_MAX_ROWS) return FMI_ERR_UNSUPPORTED;
   }
+  hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += ENTRY_CHUNK) {
     PrepArgs a;
     const int n = count - base < ENTRY_CHUNK ? count - base : ENTRY_CHUNK;
-    for (int i = 0; i < n; ++i) a.e[i] = entries[base + i];
-    hipLaunchKernelGGL(weight_prepare_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    int max_w = 1, max_r = 1, any_sn = 0;
+    int64_t max_t = 1;
+    for (int i = 0; i < n; ++i) {
+      a.e[i] = entries[base + i];
+      const int w = a.e[i].C * a.e[i].taps;
+      if (w > max_w) max_w = w;
+      if (a.e[i].rows > max_r) max_r = a.e[i].rows;
+      if ((int64_t)w * a.e[i].rows > max_t) max_t = (int64_t)w * a.e[i].rows;
+      if (a.e[i].u) any_sn = 1;
+    }
+    if (any_sn) {
+      hipLaunchKernelGGL(wp_wtu_kernel, dim3((max_w + 255) / 256, n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(wp_vnorm_kernel, dim3(n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(wp_wv_kernel, dim3((max_r + 3) / 4, n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(wp_unorm_kernel, dim3(n), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(wp_pack_kernel, dim3((unsigned)ceil_div64(max_t, PACK_PER_BLOCK), n), dim3(256), 0, st, a);
   }
   return fmi_launch_status();
 }
 
 // dW = dWeff / sigma - (sum dWeff o W) / sigma^2 * u v^T      (u, v read live)
-__global__ void __launch_bounds__(256) weight_grad_kernel(const GradArgs args) {
-  const fmi_weight_grad_entry* entries = args.e;
+// stage 1: dots[e] += partial sum of dWeff o W ; stage 2: the element-wise formula
+__global__ void __launch_bounds__(256) wg_dot_kernel(const GradArgs args, float* __restrict__ dots) {
   __shared__ float red[4];
-  const fmi_weight_grad_entry e = entries[blockIdx.x];
+  const fmi_weight_grad_entry e = args.e[blockIdx.y];
+  if (!e.u) return;
   const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
-  const int tid = threadIdx.x;
-  const int64_t total = (int64_t)rows * width;
+  const int64_t total = (int64_t)rows * width, base = (int64_t)blockIdx.x * PACK_PER_BLOCK;
+  if (base >= total) return;
+  float s = 0.f;
+  for (int64_t o = base + threadIdx.x; o < base + PACK_PER_BLOCK && o < total; o += 256) {  // o indexes dwf: [tap][c][row]
+    const int r = (int)(o % rows);
+    const int64_t q = o / rows;
+    const int c = (int)(q % C), tap = (int)(q / C);
+    s += e.dwf[o] * e.w[(int64_t)r * width + c * taps + tap];
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) atomicAdd(dots + blockIdx.y, s);
+}
+__global__ void __launch_bounds__(256) wg_apply_kernel(const GradArgs args, const float* __restrict__ dots) {
+  const fmi_weight_grad_entry e = args.e[blockIdx.y];
+  const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
+  const int64_t total = (int64_t)rows * width, base = (int64_t)blockIdx.x * PACK_PER_BLOCK;
+  if (base >= total) return;
   float sigma = 1.f, coef = 0.f;
   if (e.u) {
     sigma = e.sigma[0];
-    float s = 0.f;
-    for (int64_t o = tid; o < total; o += 256) {  // o indexes dwf: [tap][c][row]
-      const int r = (int)(o % rows);
-      const int64_t q = o / rows;
-      const int c = (int)(q % C), tap = (int)(q / C);
-      s += e.dwf[o] * e.w[(int64_t)r * width + c * taps + tap];
-    }
-    s = block_sum_256(s, red);
-    coef = s / (sigma * sigma);
+    coef = dots[blockIdx.y] / (sigma * sigma);
   }
-  for (int64_t o = tid; o < total; o += 256) {  // o indexes dw: [row][c][tap]
+  for (int64_t o = base + threadIdx.x; o < base + PACK_PER_BLOCK && o < total; o += 256) {  // o indexes dw: [row][c][tap]
     const int j = (int)(o % width);
     const int r = (int)(o / width);
     const int c = j / taps, tap = j - c * taps;
@@ -132,18 +172,28 @@ __global__ void __launch_bounds__(256) weight_grad_kernel(const GradArgs args) {
     e.dw[o] = g;
   }
 }
-extern "C" int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, void* stream) {
-  if (!entries || count <= 0) return FMI_ERR_BAD_ARG;
+extern "C" int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, float* scratch_zeroed, void* stream) {
+  if (!entries || count <= 0 || !scratch_zeroed) return FMI_ERR_BAD_ARG;
   for (int i = 0; i < count; ++i) {
     const fmi_weight_grad_entry& e = entries[i];
     if (!e.w || !e.dwf || !e.dw || e.rows <= 0 || e.C <= 0 || e.taps <= 0) return FMI_ERR_BAD_ARG;
     if (e.u && (!e.v || !e.sigma)) return FMI_ERR_BAD_ARG;
   }
+  hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += ENTRY_CHUNK) {
     GradArgs a;
     const int n = count - base < ENTRY_CHUNK ? count - base : ENTRY_CHUNK;
-    for (int i = 0; i < n; ++i) a.e[i] = entries[base + i];
-    hipLaunchKernelGGL(weight_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, a);
+    int64_t max_t = 1;
+    int any_sn = 0;
+    for (int i = 0; i < n; ++i) {
+      a.e[i] = entries[base + i];
+      const int64_t t = (int64_t)a.e[i].C * a.e[i].taps * a.e[i].rows;
+      if (t > max_t) max_t = t;
+      if (a.e[i].u) any_sn = 1;
+    }
+    const dim3 grid((unsigned)ceil_div64(max_t, PACK_PER_BLOCK), n);
+    if (any_sn) hipLaunchKernelGGL(wg_dot_kernel, grid, dim3(256), 0, st, a, scratch_zeroed + base);
+    hipLaunchKernelGGL(wg_apply_kernel, grid, dim3(256), 0, st, a, (const float*)(scratch_zeroed + base));
   }
   return fmi_launch_status();
 }

@@ -131,8 +131,8 @@ class _WeightPrepare(torch.autograd.Function):
         for i, (w, (u, v)) in enumerate(zip(ws, metas)):
             _chk(w, u, v)
             rows, cc, kh, kw = w.shape
-            if u is not None and (rows > 1024 or cc * kh * kw > 8192):
-                raise FmiError("spectral-norm weight too large for the single-workgroup kernel")
+            if u is not None and rows > 4096:
+                raise FmiError("spectral-norm weight with more than 4096 rows")
             wf = torch.empty((kh * kw, cc, rows), device=dev, dtype=torch.float32)
             wt = torch.empty((kh * kw, rows, cc), device=dev, dtype=torch.float32)
             e = entries[i]
@@ -176,7 +176,8 @@ class _WeightPrepare(torch.autograd.Function):
                 e.dw = dw.data_ptr()
                 e.rows, e.C, e.taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
                 grads[i] = dw
-            lib.weight_grad_f32(entries, len(live), _st())
+            scratch = torch.zeros(len(live), device=ctx.sig.device, dtype=torch.float32)
+            lib.weight_grad_f32(entries, len(live), _p(scratch), _st())
         return (None,) + tuple(grads)
 
 
@@ -596,16 +597,21 @@ def vae_sample(o_src, o_ref, eps_q, eps_p):
 # attention:  A = softmax(Q Q^T) ;  O_i = A V_i        (Q [N,T,d], V_i [N,T,C_i])
 # chunked over query rows so that one score chunk stays inside the Infinity Cache
 # ---------------------------------------------------------------------------------------------------
-def _attn_chunk(n, t):
-    rows = ATTN_CHUNK_BYTES // (n * t * 4)
-    rows = max(128, (rows // 128) * 128)
-    return min(t, rows)
+def _attn_plan(n, t, budget):
+    """(images per group, query rows per chunk): long reductions for the P^T dO / dS^T Q products want many rows per
+    chunk, so images are processed in groups rather than all at once with 128-row chunks"""
+    qc = min(t, 512)
+    if qc * t * 4 > budget:
+        qc = max(128, (budget // (t * 4) // 128) * 128)
+        qc = min(t, qc)
+    ng = max(1, min(n, budget // (qc * t * 4)))
+    return ng, qc
 
 
-def _scores(q, n, t, d, q0, qc, buf):
-    # S[b, i, j] = q[b, q0+i, :] . q[b, j, :]
-    gemm_raw(_p(q, q0 * d), _p(q), _p(buf), qc, t, d, (d, 1), (1, d), (t, 1), n, (t * d, t * d, qc * t), tag="attn_qk")
-    _L().softmax_rows_f32(_p(buf), _p(buf), n * qc, t, _st())
+def _scores(q, ng, t, d, n0, q0, qc, buf):
+    # S[b, i, j] = q[n0+b, q0+i, :] . q[n0+b, j, :]
+    gemm_raw(_p(q, (n0 * t + q0) * d), _p(q, n0 * t * d), _p(buf), qc, t, d, (d, 1), (1, d), (t, 1), ng, (t * d, t * d, qc * t), tag="attn_qk")
+    _L().softmax_rows_f32(_p(buf), _p(buf), ng * qc, t, _st())
 
 
 class _SelfAttention(torch.autograd.Function):
@@ -613,15 +619,18 @@ class _SelfAttention(torch.autograd.Function):
     def forward(ctx, q, *vs):
         _chk(q, *vs)
         n, t, d = q.shape
-        qc_max = _attn_chunk(n, t)
-        buf = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
+        ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES)
+        buf = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         outs = [torch.empty_like(v) for v in vs]
-        for q0 in range(0, t, qc_max):
-            qc = min(qc_max, t - q0)
-            _scores(q, n, t, d, q0, qc, buf)
-            for v, o in zip(vs, outs):
-                c = v.shape[2]
-                gemm_raw(_p(buf), _p(v), _p(o, q0 * c), qc, c, t, (t, 1), (c, 1), (c, 1), n, (qc * t, t * c, t * c), tag="attn_pv")
+        for n0 in range(0, n, ngm):
+            ng = min(ngm, n - n0)
+            for q0 in range(0, t, qcm):
+                qc = min(qcm, t - q0)
+                _scores(q, ng, t, d, n0, q0, qc, buf)
+                for v, o in zip(vs, outs):
+                    c = v.shape[2]
+                    gemm_raw(_p(buf), _p(v, n0 * t * c), _p(o, (n0 * t + q0) * c), qc, c, t, (t, 1), (c, 1), (c, 1), ng,
+                             (qc * t, t * c, t * c), tag="attn_pv")
         ctx.save_for_backward(q, *vs)
         return tuple(outs)
 
@@ -629,32 +638,37 @@ class _SelfAttention(torch.autograd.Function):
     def backward(ctx, *gos):
         q, *vs = ctx.saved_tensors
         n, t, d = q.shape
-        qc_max = max(128, (_attn_chunk(n, t) // 2 // 128) * 128)
-        qc_max = min(t, qc_max)
-        P = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
-        dP = torch.empty(n * qc_max * t, device=q.device, dtype=torch.float32)
+        ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES // 2)
+        P = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
+        dP = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         gos = [g.contiguous() if g is not None else None for g in gos]
         gq = torch.zeros_like(q)
         gvs = [torch.zeros_like(v) if g is not None else None for v, g in zip(vs, gos)]
-        for q0 in range(0, t, qc_max):
-            qc = min(qc_max, t - q0)
-            _scores(q, n, t, d, q0, qc, P)
-            first = True
-            for v, g, gv in zip(vs, gos, gvs):
-                if g is None:
-                    continue
-                c = v.shape[2]
-                # dV += P^T dO_chunk
-                gemm_raw(_p(P), _p(g, q0 * c), _p(gv), t, c, qc, (1, t), (c, 1), (c, 1), n, (qc * t, t * c, t * c), 1.0, 1.0, tag="attn_bwd_dv")
-                # dP (+)= dO_chunk V^T
-                gemm_raw(_p(g, q0 * c), _p(v), _p(dP), qc, t, c, (c, 1), (1, c), (t, 1), n, (t * c, t * c, qc * t), 1.0, 0.0 if first else 1.0, tag="attn_bwd_dp")
-                first = False
-            if first:
-                continue
-            _L().softmax_rows_bwd_f32(_p(P), _p(dP), _p(dP), n * qc, t, _st())
-            # query side: dQ[chunk] += dS Q ; key side: dQ += dS^T Q[chunk]
-            gemm_raw(_p(dP), _p(q), _p(gq, q0 * d), qc, d, t, (t, 1), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dq")
-            gemm_raw(_p(dP), _p(q, q0 * d), _p(gq), t, d, qc, (1, t), (d, 1), (d, 1), n, (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dk")
+        if all(g is None for g in gos):
+            return (gq,) + tuple(gvs)
+        for n0 in range(0, n, ngm):
+            ng = min(ngm, n - n0)
+            for q0 in range(0, t, qcm):
+                qc = min(qcm, t - q0)
+                _scores(q, ng, t, d, n0, q0, qc, P)
+                first = True
+                for v, g, gv in zip(vs, gos, gvs):
+                    if g is None:
+                        continue
+                    c = v.shape[2]
+                    # dV += P^T dO_chunk
+                    gemm_raw(_p(P), _p(g, (n0 * t + q0) * c), _p(gv, n0 * t * c), t, c, qc, (1, t), (c, 1), (c, 1), ng,
+                             (qc * t, t * c, t * c), 1.0, 1.0, tag="attn_bwd_dv")
+                    # dP (+)= dO_chunk V^T
+                    gemm_raw(_p(g, (n0 * t + q0) * c), _p(v, n0 * t * c), _p(dP), qc, t, c, (c, 1), (1, c), (t, 1), ng,
+                             (t * c, t * c, qc * t), 1.0, 0.0 if first else 1.0, tag="attn_bwd_dp")
+                    first = False
+                _L().softmax_rows_bwd_f32(_p(P), _p(dP), _p(dP), ng * qc, t, _st())
+                # query side: dQ[chunk] += dS Q ; key side: dQ += dS^T Q[chunk]
+                gemm_raw(_p(dP), _p(q, n0 * t * d), _p(gq, (n0 * t + q0) * d), qc, d, t, (t, 1), (d, 1), (d, 1), ng,
+                         (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dq")
+                gemm_raw(_p(dP), _p(q, (n0 * t + q0) * d), _p(gq, n0 * t * d), t, d, qc, (1, t), (d, 1), (d, 1), ng,
+                         (qc * t, t * d, t * d), 1.0, 1.0, tag="attn_bwd_dk")
         return (gq,) + tuple(gvs)
 
 

@@ -123,7 +123,8 @@ typedef struct {
   float* dw;           /* out [rows][C*taps], overwritten */
   int rows, C, taps, pad_;
 } fmi_weight_grad_entry;
-int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, void* stream);  /* HOST array */
+/* entries: HOST array; scratch_zeroed: DEVICE float[count], zero on entry (holds sum dWeff o W per tensor) */
+int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, float* scratch_zeroed, void* stream);
 
 /* ------------------------------------------------------------------------
  * Row softmax over the last dimension (base_function.py:412,430,

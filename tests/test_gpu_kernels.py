@@ -298,7 +298,7 @@ def test_softmax_rows(dev, FF):
 @pytest.mark.parametrize("n,t,d,cs", [(2, 64, 8, (16, 16)), (1, 300, 16, (32,)), (2, 1024, 32, (128, 128))])
 def test_self_attention(dev, FF, n, t, d, cs, monkeypatch):
     """softmax(q q^T) v, forward and backward, including the multi-chunk path"""
-    monkeypatch.setattr(FF, "ATTN_CHUNK_BYTES", n * t * 4 * 128 * 2)  # force several query chunks
+    monkeypatch.setattr(FF, "ATTN_CHUNK_BYTES", t * 4 * 128 * 2)  # force several query chunks and image groups
     g = torch.Generator().manual_seed(8)
     q = (torch.randn(n, t, d, generator=g) * 0.7).requires_grad_(True)
     vs = [torch.randn(n, t, c, generator=g).requires_grad_(True) for c in cs]
