@@ -182,7 +182,7 @@ def test_two_training_steps_against_reference_golden(dev, golden):
         for k, v in fx[key].items():
             d = (sd[k].cpu() - v).abs()
             assert d.max() <= 2.2 * cfg["lr"], f"{key} {k}: max diff {d.max():.3e}"
-            assert (d > 2e-4).float().mean() <= 0.01, f"{key} {k}: {(d > 2e-4).sum()} of {d.numel()} elements off by > 2e-4"
+            assert (d > 2e-4).sum() <= max(2, 0.01 * d.numel()), f"{key} {k}: {(d > 2e-4).sum()} of {d.numel()} elements off by > 2e-4"
 
 
 def test_forward_matches_oracle_at_moderate_size(dev):
