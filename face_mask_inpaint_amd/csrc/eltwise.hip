@@ -18,11 +18,13 @@ __device__ __forceinline__ float ew_op(float a, float b, float p0) {
   if (OP == FMI_EW_SOFTPLUS) return a > 20.f ? a : log1pf(expf(a));
   if (OP == FMI_EW_SOFTPLUS_BWD) return b > 20.f ? a : a / (1.f + expf(-b));
   if (OP == FMI_EW_SUB) return a - b;
+  if (OP == FMI_EW_RSQRT) return 1.f / sqrtf(a + p0);
+  if (OP == FMI_EW_RSQRT_BWD) return -0.5f * a * b * b * b;
   return 0.f;
 }
 template <int OP>
 constexpr bool ew_binary() {
-  return !(OP == FMI_EW_LRELU || OP == FMI_EW_SCALE || OP == FMI_EW_SOFTPLUS);
+  return !(OP == FMI_EW_LRELU || OP == FMI_EW_SCALE || OP == FMI_EW_SOFTPLUS || OP == FMI_EW_RSQRT);
 }
 
 template <int OP, bool VEC>
@@ -75,6 +77,8 @@ extern "C" int fmi_eltwise_f32(int op, const float* a, const float* b, float* y,
     case FMI_EW_SOFTPLUS: return launch_ew<FMI_EW_SOFTPLUS>(a, b, y, n, p0, st);
     case FMI_EW_SOFTPLUS_BWD: return launch_ew<FMI_EW_SOFTPLUS_BWD>(a, b, y, n, p0, st);
     case FMI_EW_SUB: return launch_ew<FMI_EW_SUB>(a, b, y, n, p0, st);
+    case FMI_EW_RSQRT: return launch_ew<FMI_EW_RSQRT>(a, b, y, n, p0, st);
+    case FMI_EW_RSQRT_BWD: return launch_ew<FMI_EW_RSQRT_BWD>(a, b, y, n, p0, st);
     default: return FMI_ERR_UNSUPPORTED;
   }
 }

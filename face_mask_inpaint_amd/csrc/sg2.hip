@@ -1,0 +1,150 @@
+// StyleGAN2 decoder helpers on NHWC activations (stylegan2/model.py:187-369): the modulation is applied to the
+// ACTIVATIONS (x * s[n,c] before the conv, * demod[n,o] after it), which is algebraically the reference's
+// per-sample weight modulation (model.py:244-250) but lets every sample share one packed weight and one GEMM.
+// All kernels are bandwidth-class.
+#include "common.h"
+
+// y[n][p][c] = x[n][p][c] * s[n][c]
+__global__ void __launch_bounds__(256) scale_channels_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                             float* __restrict__ y, int64_t P, int C, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t n = i / (P * C);
+    y[i] = x[i] * s[n * C + c];
+  }
+}
+extern "C" int fmi_scale_channels_f32(const float* x, const float* s, float* y, int N, int64_t P, int C, void* stream) {
+  if (!x || !s || !y || N <= 0 || P <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)N * P * C;
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, P, C, total);
+  return fmi_launch_status();
+}
+// gs[n][c] += sum_p g[n][p][c] * x[n][p][c]     (caller zeroes gs)
+__global__ void __launch_bounds__(256) scale_channels_gs_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                float* __restrict__ gs, int64_t P, int C, int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const float* gb = g + (int64_t)n * P * C;
+  const float* xb = x + (int64_t)n * P * C;
+  for (int cg = 0; cg < C; cg += 64) {
+    const int c = cg + tx;
+    float s = 0.f;
+    if (c < C)
+      for (int64_t r = r0 + ty; r < r1; r += 4) s += gb[r * C + c] * xb[r * C + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(gs + (int64_t)n * C + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    __syncthreads();
+  }
+}
+extern "C" int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, int N, int64_t P, int C, void* stream) {
+  if (!g || !x || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  int64_t blocks = ceil_div64(P, 128);
+  if (blocks > 1024) blocks = 1024;
+  const int64_t rpb = ceil_div64(P, blocks);
+  blocks = ceil_div64(P, rpb);
+  hipLaunchKernelGGL(scale_channels_gs_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, g, x, gs, P, C, rpb);
+  return fmi_launch_status();
+}
+
+// out[r] = sum_k x[r][k]^2  and its gradient gx[r][k] = 2 x[r][k] g[r]     (W^2 summed over the taps)
+__global__ void __launch_bounds__(256) sqsum_last_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int k) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) s += x[r * k + j] * x[r * k + j];
+    out[r] = s;
+  }
+}
+extern "C" int fmi_sqsum_last_f32(const float* x, float* out, int64_t rows, int k, void* stream) {
+  if (!x || !out || rows <= 0 || k <= 0) return FMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sqsum_last_kernel, dim3(fmi_bw_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, out, rows, k);
+  return fmi_launch_status();
+}
+__global__ void __launch_bounds__(256) sqsum_last_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             float* __restrict__ gx, int64_t total, int k) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) gx[i] = 2.f * x[i] * g[i / k];
+}
+extern "C" int fmi_sqsum_last_bwd_f32(const float* x, const float* g, float* gx, int64_t rows, int k, void* stream) {
+  if (!x || !g || !gx || rows <= 0 || k <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = rows * k;
+  hipLaunchKernelGGL(sqsum_last_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, g, gx, total, k);
+  return fmi_launch_status();
+}
+
+// backward of y = lrelu(x + bias[c] + nw*noise[p]) * scale:  gx = g * scale * (y > 0 ? 1 : alpha);  gnw += sum gx*noise
+__global__ void __launch_bounds__(256) noise_bias_act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                 const float* __restrict__ noise, float* __restrict__ gx,
+                                                                 float* __restrict__ gnw, int64_t total, int C, float alpha,
+                                                                 float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = g[i] * scale * (y[i] > 0.f ? 1.f : alpha);
+    gx[i] = v;
+    if (noise) acc += v * noise[i / C];
+  }
+  if (noise && gnw) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(gnw, acc);
+  }
+}
+extern "C" int fmi_noise_bias_act_bwd_f32(const float* g, const float* y, const float* noise, float* gx, float* gnw,
+                                          int64_t pixels, int C, float alpha, float scale, void* stream) {
+  if (!g || !y || !gx || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = pixels * C;
+  hipLaunchKernelGGL(noise_bias_act_bwd_kernel, dim3(fmi_bw_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, y, noise,
+                     gx, gnw, total, C, alpha, scale);
+  return fmi_launch_status();
+}
+
+// upfirdn2d on NHWC tensors (minor dimension = channels): same semantics as fmi_upfirdn2d_f32 per (n, c) plane
+__device__ __forceinline__ int fdiv_i(int a, int b) {
+  int q = a / b;
+  if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+  return q;
+}
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ kernel,
+                                                             float* __restrict__ out, int in_h, int in_w, int C, int out_h,
+                                                             int out_w, int kh, int kw, int up_x, int up_y, int down_x,
+                                                             int down_y, int pad_x0, int pad_y0, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % out_w);
+    r /= out_w;
+    const int oy = (int)(r % out_h);
+    const int n = (int)(r / out_h);
+    const int uy0 = oy * down_y - pad_y0, ux0 = ox * down_x - pad_x0;
+    int ky0 = (-uy0) % up_y, kx0 = (-ux0) % up_x;
+    if (ky0 < 0) ky0 += up_y;
+    if (kx0 < 0) kx0 += up_x;
+    float acc = 0.f;
+    for (int ky = ky0; ky < kh; ky += up_y) {
+      const int iy = (uy0 + ky) / up_y;
+      if ((unsigned)iy >= (unsigned)in_h) continue;
+      for (int kx = kx0; kx < kw; kx += up_x) {
+        const int ix = (ux0 + kx) / up_x;
+        if ((unsigned)ix >= (unsigned)in_w) continue;
+        acc += in[(((int64_t)n * in_h + iy) * in_w + ix) * C + c] * kernel[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+      }
+    }
+    out[i] = acc;
+  }
+}
+extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int N, int in_h, int in_w, int C,
+                                      int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                      int pad_y0, int pad_y1, void* stream) {
+  if (!in || !kernel || !out || N <= 0 || in_h <= 0 || in_w <= 0 || C <= 0 || kh <= 0 || kw <= 0) return FMI_ERR_BAD_ARG;
+  if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return FMI_ERR_BAD_ARG;
+  const int fh = in_h * up_y + pad_y0 + pad_y1 - kh, fw = in_w * up_x + pad_x0 + pad_x1 - kw;
+  if (fh < 0 || fw < 0) return FMI_ERR_BAD_ARG;
+  const int out_h = fh / down_y + 1, out_w = fw / down_x + 1;
+  const int64_t total = (int64_t)N * out_h * out_w * C;
+  hipLaunchKernelGGL(upfirdn2d_nhwc_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, kernel, out, in_h,
+                     in_w, C, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, total);
+  return fmi_launch_status();
+}

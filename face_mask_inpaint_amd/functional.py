@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, FmiError
 
-EW_LRELU, EW_LRELU_BWD, EW_TANH_BWD, EW_ADD, EW_SCALE, EW_AXPY, EW_MUL, EW_RELU_BWD_OUT, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_SUB = range(11)
+EW_LRELU, EW_LRELU_BWD, EW_TANH_BWD, EW_ADD, EW_SCALE, EW_AXPY, EW_MUL, EW_RELU_BWD_OUT, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_SUB, EW_RSQRT, EW_RSQRT_BWD = range(13)
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 
 # scratch budget for one attention score chunk (kept well inside the 256 MB Infinity Cache)
@@ -795,6 +795,217 @@ class _ContextualLoss(torch.autograd.Function):
 
 def contextual_loss(x_npc, y_npc, h=0.5, scale=1.0):
     return _ContextualLoss.apply(x_npc.contiguous(), y_npc.contiguous(), h, scale)
+
+
+# ---------------------------------------------------------------------------------------------------
+# StyleGAN2 decoder pieces (NHWC)
+# ---------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = alpha * x W^T + bias   (x [N,K], W [O,K]) -- EqualLinear, stylegan2/model.py:160-165"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, alpha):
+        _chk(x, w, bias)
+        n, k = x.shape
+        o = w.shape[0]
+        y = torch.empty((n, o), device=x.device, dtype=torch.float32)
+        gemm_raw(_p(x), _p(w), _p(y), n, o, k, (k, 1), (1, k), (o, 1), alpha=alpha, bias=bias, tag="linear")
+        ctx.save_for_backward(x, w)
+        ctx.alpha, ctx.has_bias = alpha, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        n, k = x.shape
+        o = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            gemm_raw(_p(g), _p(w), _p(gx), n, k, o, (o, 1), (k, 1), (k, 1), alpha=ctx.alpha, tag="linear_bwd")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            gemm_raw(_p(g), _p(x), _p(gw), o, k, n, (1, o), (k, 1), (k, 1), alpha=ctx.alpha, tag="linear_bwd")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros(o, device=g.device, dtype=torch.float32)
+            _L().bias_grad_f32(_p(g), n, o, o, _p(gb), _st())
+        return gx, gw, gb, None
+
+
+def linear(x, w, bias=None, alpha=1.0):
+    return _Linear.apply(x.contiguous(), w.contiguous(), bias, float(alpha))
+
+
+class _ScaleChannels(torch.autograd.Function):
+    """y[n,p,c] = x[n,p,c] * s[n,c]"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        _chk(x, s)
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        y = torch.empty_like(x)
+        _L().scale_channels_f32(_p(x), _p(s), _p(y), n, p, c, _st())
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        gx = gs = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _L().scale_channels_f32(_p(g), _p(s), _p(gx), n, p, c, _st())
+        if ctx.needs_input_grad[1]:
+            gs = torch.zeros_like(s)
+            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), n, p, c, _st())
+        return gx, gs
+
+
+def scale_channels(x, s):
+    return _ScaleChannels.apply(x, s.contiguous())
+
+
+class _SqSumLast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        rows, k = x.shape
+        out = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _L().sqsum_last_f32(_p(x), _p(out), rows, k, _st())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        _L().sqsum_last_bwd_f32(_p(x), _p(g.contiguous()), _p(gx), x.shape[0], x.shape[1], _st())
+        return gx
+
+
+def sqsum_last(x2d):
+    """sum of squares over the last dimension of a [rows, k] tensor"""
+    return _SqSumLast.apply(x2d.contiguous())
+
+
+class _RsqrtEps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y = eltwise(EW_RSQRT, x, None, eps)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return eltwise(EW_RSQRT_BWD, g.contiguous(), y), None
+
+
+def rsqrt_eps(x, eps):
+    return _RsqrtEps.apply(x.contiguous(), float(eps))
+
+
+class _Scale(torch.autograd.Function):
+    """y = c * a for a python constant c"""
+
+    @staticmethod
+    def forward(ctx, a, c):
+        ctx.c = c
+        return eltwise(EW_SCALE, a.contiguous(), None, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return eltwise(EW_SCALE, g.contiguous(), None, ctx.c), None
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return eltwise(EW_MUL, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        return eltwise(EW_MUL, g, b), eltwise(EW_MUL, g, a)
+
+
+def mul(a, b):
+    return _Mul.apply(a.contiguous(), b.contiguous())
+
+
+class _NoiseBiasAct(torch.autograd.Function):
+    """y = lrelu(x + bias[c] + nw * noise[p], alpha) * scale   (NoiseInjection + FusedLeakyReLU, model.py:282-346)"""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise, nw, alpha, scale):
+        _chk(x, bias, noise, nw)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _L().noise_bias_act_f32(_p(x), _p(bias), _p(noise), _p(nw), _p(y), x.numel() // c, c, alpha, scale, _st())
+        ctx.save_for_backward(y, noise)
+        ctx.cfg = (alpha, scale, bias is not None, nw is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, noise = ctx.saved_tensors
+        alpha, scale, has_b, has_nw = ctx.cfg
+        g = g.contiguous()
+        c = y.shape[-1]
+        gx = torch.empty_like(y)
+        gnw = torch.zeros(1, device=y.device, dtype=torch.float32) if (has_nw and noise is not None) else None
+        _L().noise_bias_act_bwd_f32(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), y.numel() // c, c, alpha, scale, _st())
+        gb = None
+        if has_b and ctx.needs_input_grad[1]:
+            gb = torch.zeros(c, device=y.device, dtype=torch.float32)
+            _L().bias_grad_f32(_p(gx), y.numel() // c, c, c, _p(gb), _st())
+        return gx, gb, None, gnw, None, None
+
+
+def noise_bias_act(x, bias, noise=None, nw=None, alpha=0.2, scale=2 ** 0.5):
+    return _NoiseBiasAct.apply(x, bias, noise, nw, float(alpha), float(scale))
+
+
+class _UpFirDnNHWC(torch.autograd.Function):
+    """upfirdn2d on [N,H,W,C]; the gradient is the same op with the flipped kernel, up/down swapped and the g_pad of
+    op/upfirdn2d.py:108-113."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad):
+        _chk(x, kernel)
+        n, h, w, c = x.shape
+        kh, kw = kernel.shape
+        oh = (h * up + pad[0] + pad[1] - kh) // down + 1
+        ow = (w * up + pad[0] + pad[1] - kw) // down + 1
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        _L().upfirdn2d_nhwc_f32(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad, (n, h, w, c), (oh, ow))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (kernel,) = ctx.saved_tensors
+        up, down, pad, (n, h, w, c), (oh, ow) = ctx.cfg
+        kh, kw = kernel.shape
+        gk = torch.flip(kernel, [0, 1]).contiguous()
+        gx0, gy0 = kw - pad[0] - 1, kh - pad[0] - 1
+        gx1 = w * up - ow * down + pad[0] - up + 1
+        gy1 = h * up - oh * down + pad[0] - up + 1
+        gx = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
+        _L().upfirdn2d_nhwc_f32(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
+        return gx, None, None, None, None
+
+
+def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0)):
+    return _UpFirDnNHWC.apply(x, kernel.contiguous(), int(up), int(down), (int(pad[0]), int(pad[1])))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -149,6 +149,8 @@ enum {
   FMI_EW_SOFTPLUS = 8,     /* y = log1p(exp(a)) (threshold 20, F.softplus) */
   FMI_EW_SOFTPLUS_BWD = 9, /* y = a * sigmoid(b)              b = forward input */
   FMI_EW_SUB = 10,         /* y = a - b */
+  FMI_EW_RSQRT = 11,       /* y = rsqrt(a + p0) */
+  FMI_EW_RSQRT_BWD = 12,   /* y = -0.5 * a * b^3          a = grad, b = forward output */
   FMI_EW_COUNT_
 };
 int fmi_eltwise_f32(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream);
@@ -259,6 +261,22 @@ int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbia
 /* NHWC variant used by the product's StyledConv: y = lrelu(x + bias[c] + nw[0]*noise[p]) * scale */
 int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise, const float* nw, float* y,
                            int64_t pixels, int C, float alpha, float scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * StyleGAN2 decoder on NHWC activations (stylegan2/model.py:187-369).  ModulatedConv2d is evaluated as
+ * demod[n,o] * conv(x * s[n,c], W): algebraically the reference's per-sample weight modulation (model.py:244-250).
+ * ---------------------------------------------------------------------- */
+int fmi_scale_channels_f32(const float* x, const float* s, float* y, int N, int64_t P, int C, void* stream);       /* y[n,p,c] = x * s[n,c] */
+int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, int N, int64_t P, int C, void* stream);   /* gs[n,c] += sum_p g*x */
+int fmi_sqsum_last_f32(const float* x, float* out, int64_t rows, int k, void* stream);                             /* out[r] = sum_k x[r,k]^2 */
+int fmi_sqsum_last_bwd_f32(const float* x, const float* g, float* gx, int64_t rows, int k, void* stream);
+/* backward of fmi_noise_bias_act_f32: gx = g*scale*(y>0?1:alpha); gnw[0] += sum gx*noise[p] (noise/gnw may be NULL) */
+int fmi_noise_bias_act_bwd_f32(const float* g, const float* y, const float* noise, float* gx, float* gnw,
+                               int64_t pixels, int C, float alpha, float scale, void* stream);
+/* upfirdn2d with minor dimension = channels: in [N,in_h,in_w,C] -> out [N,out_h,out_w,C] */
+int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int N, int in_h, int in_w, int C,
+                           int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                           int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
 #ifdef __cplusplus
 }

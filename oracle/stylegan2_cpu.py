@@ -134,3 +134,21 @@ def to_rgb(P, prefix, x, style, skip=None):
         k = make_kernel([1, 3, 3, 1]) * 4
         out = out + upfirdn2d_t(skip, k, up=2, pad=(2, 1))
     return out
+
+
+def generator_forward(P, latent, noises, size):
+    """Generator.forward with input_is_latent=True and explicit per-layer noises (stylegan2/model.py:479-550).
+    Composition of the block functions above (which are pinned by the golden fixtures); the whole generator is not
+    pinned by a fixture of its own (its 512-channel layers would make it >100 MB)."""
+    n = latent.shape[0]
+    log_size = int(math.log2(size))
+    out = P["input.input"].repeat(n, 1, 1, 1)
+    out = styled_conv(P, "conv1", out, latent[:, 0], noises[0])
+    skip = to_rgb(P, "to_rgb1", out, latent[:, 1])
+    i = 1
+    for l in range(log_size - 2):
+        out = styled_conv(P, f"convs.{2 * l}", out, latent[:, i], noises[1 + 2 * l], upsample=True)
+        out = styled_conv(P, f"convs.{2 * l + 1}", out, latent[:, i + 1], noises[2 + 2 * l])
+        skip = to_rgb(P, f"to_rgbs.{l}", out, latent[:, i + 2], skip)
+        i += 2
+    return skip

@@ -96,3 +96,84 @@ def test_fused_leaky_relu(dev, golden):
         yd.backward(gy.to(dev))
         torch.testing.assert_close(xd.grad.cpu(), xx.grad, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(m.bias.grad.cpu(), bb.grad, rtol=1e-5, atol=1e-5)
+
+
+# ---- StyleGAN2 decoder modules (rows B3-B6 of SURVEY.md section 8a) ---------------------------------------
+def _grads_close(mod, ref, rtol=2e-4, atol=2e-5):
+    params = dict(mod.named_parameters())
+    for n, g in ref.items():
+        torch.testing.assert_close(params[n].grad.cpu(), g, rtol=rtol, atol=atol, msg=lambda m, n=n: f"{n}: {m}")
+
+
+def test_modulated_conv_blocks_against_reference_golden(dev, golden):
+    from face_mask_inpaint_amd.modules.psp.stylegan2 import model as sg
+
+    fx = golden("stylegan2_ops.pt")
+    torch.manual_seed(0)
+    for name, mk in (("modconv", lambda: sg.ModulatedConv2d(8, 12, 3, 16)), ("modconv_up", lambda: sg.ModulatedConv2d(8, 6, 3, 16, upsample=True)),
+                     ("modconv_rgb", lambda: sg.ModulatedConv2d(8, 3, 1, 16, demodulate=False))):
+        f = fx[name]
+        m = mk()
+        m.load_state_dict(f["sd"])
+        m = m.to(dev)
+        x, s = f["x"].to(dev).requires_grad_(True), f["style"].to(dev).requires_grad_(True)
+        y = m(x, s)
+        torch.testing.assert_close(y.detach().cpu(), f["out"], rtol=1e-4, atol=1e-5)
+        y.backward(f["gout"].to(dev))
+        torch.testing.assert_close(x.grad.cpu(), f["gx"], rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(s.grad.cpu(), f["gstyle"], rtol=2e-4, atol=2e-5)
+        _grads_close(m, f["gparams"])
+    f = fx["styledconv_up"]
+    m = sg.StyledConv(8, 12, 3, 16, upsample=True)
+    m.load_state_dict(f["sd"])
+    m = m.to(dev)
+    x, s = f["x"].to(dev).requires_grad_(True), f["style"].to(dev).requires_grad_(True)
+    y = m(x, s, noise=f["noise"].to(dev))
+    torch.testing.assert_close(y.detach().cpu(), f["out"], rtol=1e-4, atol=1e-5)
+    y.backward(f["gout"].to(dev))
+    torch.testing.assert_close(x.grad.cpu(), f["gx"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(s.grad.cpu(), f["gstyle"], rtol=2e-4, atol=2e-5)
+    _grads_close(m, f["gparams"])
+    f = fx["torgb"]
+    m = sg.ToRGB(8, 16)
+    m.load_state_dict(f["sd"])
+    m = m.to(dev)
+    x, s, sk = f["x"].to(dev).requires_grad_(True), f["style"].to(dev).requires_grad_(True), f["skip"].to(dev).requires_grad_(True)
+    y = m(x, s, sk)
+    torch.testing.assert_close(y.detach().cpu(), f["out"], rtol=1e-4, atol=1e-5)
+    y.backward(f["gout"].to(dev))
+    torch.testing.assert_close(x.grad.cpu(), f["gx"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(s.grad.cpu(), f["gstyle"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(sk.grad.cpu(), f["gskip"], rtol=2e-4, atol=2e-5)
+    _grads_close(m, f["gparams"])
+
+
+def test_generator_against_oracle(dev):
+    """Generator(16, 64, 2): constant input -> conv1/to_rgb1 -> two octaves, fixed noise buffers, W+ latents"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2 import model as sg
+    from oracle import stylegan2_cpu as S  # checker
+
+    torch.manual_seed(3)
+    gen = sg.Generator(16, 64, 2)
+    with torch.no_grad():
+        for n_, p in gen.named_parameters():
+            if n_.endswith("noise.weight"):
+                p.fill_(0.1)
+    P = {k: v.clone() for k, v in gen.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(2, gen.n_latent, 64, generator=g)
+    noises = [getattr(gen.noises, f"noise_{i}").clone() for i in range(gen.num_layers)]
+    want = S.generator_forward(P, lat, noises, 16)
+    gen = gen.to(dev)
+    latd = lat.to(dev).requires_grad_(True)
+    img, _ = gen([latd], input_is_latent=True, randomize_noise=False)
+    torch.testing.assert_close(img.detach().cpu(), want, rtol=1e-3, atol=1e-4)
+    img.square().mean().backward() if False else img.backward(torch.ones_like(img))
+    assert torch.isfinite(latd.grad).all() and latd.grad.abs().sum() > 0
+    # the mapping network (PixelNorm + EqualLinear(fused_lrelu)) against plain torch
+    z = torch.randn(3, 64, generator=g)
+    w = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+    for i in (1, 2):
+        Wt, b = P[f"style.{i}.weight"], P[f"style.{i}.bias"]
+        w = torch.nn.functional.leaky_relu(torch.nn.functional.linear(w, Wt * (1 / 8.0) * 0.01) + b * 0.01, 0.2) * 2 ** 0.5
+    torch.testing.assert_close(gen.get_latent(z.to(dev)).cpu(), w, rtol=1e-4, atol=1e-5)
