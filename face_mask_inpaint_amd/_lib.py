@@ -47,6 +47,7 @@ SIGNATURES = {
     "fmi_weight_grad_f32": [vp, i32, vp, vp],
     "fmi_softmax_rows_f32": [vp, vp, i64, i32, vp],
     "fmi_softmax_rows_bwd_f32": [vp, vp, vp, i64, i32, vp],
+    "fmi_attention_fwd_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_eltwise_f32": [i32, vp, vp, vp, i64, f32, vp],
     "fmi_axpy_dev_f32": [vp, vp, vp, vp, i64, vp],
     "fmi_dot_f32": [vp, vp, i64, f32, vp, vp],

@@ -614,11 +614,35 @@ def _scores(q, ng, t, d, n0, q0, qc, buf):
     _L().softmax_rows_f32(_p(buf), _p(buf), ng * qc, t, _st())
 
 
+FUSED_ATTENTION = True  # tests flip this to cross-check the fused kernel against the GEMM + softmax composition
+
+
+def _fused_attn_ok(q, vs):
+    n, t, d = q.shape
+    if not FUSED_ATTENTION or len(vs) > 2 or t % 128 or d not in (16, 32, 64):
+        return False
+    cs = [v.shape[2] for v in vs]
+    if any(c % 32 for c in cs):
+        return False
+    return (d, sum(cs) // 32) in ((64, 8), (32, 8), (32, 4), (64, 4), (16, 2), (16, 4))
+
+
 class _SelfAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, *vs):
         _chk(q, *vs)
         n, t, d = q.shape
+        if _fused_attn_ok(q, vs):
+            outs = [torch.empty_like(v) for v in vs]
+            lse = torch.empty((n, t), device=q.device, dtype=torch.float32)
+            c1 = vs[0].shape[2]
+            c2 = vs[1].shape[2] if len(vs) > 1 else 0
+            with _prof(f"attn_fused_fwd|T{t} d{d} C{c1 + c2} b{n}", 2.0 * n * t * t * (d + c1 + c2)):
+                _L().attention_fwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if len(vs) > 1 else None, _p(outs[0]),
+                                       _p(outs[1]) if len(vs) > 1 else None, _p(lse), n, t, d, c1, c2, _st())
+            ctx.save_for_backward(q, *vs)
+            ctx.lse = lse
+            return tuple(outs)
         ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES)
         buf = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         outs = [torch.empty_like(v) for v in vs]

@@ -134,6 +134,13 @@ int fmi_softmax_rows_f32(const float* x, float* y, int64_t rows, int cols, void*
 /* ds = p * (dp - sum_j p*dp) ; ds may alias dp */
 int fmi_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t rows, int cols, void* stream);
 
+/* Fused flash-style self-attention (queries = keys, no scaling):  O_i = softmax(q q^T) V_i, V = [V1 | V2] along channels.
+ * q [N,T,D], v1 [N,T,C1], v2 [N,T,C2] or NULL, outputs o1/o2 alike, lse [N,T] = log sum_j exp(q_i.q_j) (may be NULL).
+ * Supported: T % 128 == 0, D in {16,32,64}, C1 % 32 == C2 % 32 == 0, (C1+C2)/32 in {2,4,8}; else FMI_ERR_UNSUPPORTED
+ * (callers fall back to the GEMM + softmax composition). */
+int fmi_attention_fwd_f32(const float* q, const float* v1, const float* v2, float* o1, float* o2, float* lse,
+                          int N, int T, int D, int C1, int C2, void* stream);
+
 /* ------------------------------------------------------------------------
  * Bandwidth-class element-wise kernels (float4 vectorised).
  * ---------------------------------------------------------------------- */

@@ -427,3 +427,29 @@ def test_fused_adam_matches_torch(dev):
         o_mine.step()
     for r, m in zip(ref, mine):
         torch.testing.assert_close(m.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,t,d,cs", [(2, 128, 16, (64,)), (1, 256, 32, (128,)), (2, 1024, 32, (128, 128)), (1, 512, 64, (256,)), (1, 384, 64, (64, 64))])
+def test_fused_attention_forward(dev, FF, n, t, d, cs):
+    """flash-style fused kernel against fp64 softmax(q q^T) v, incl. a query whose maximum jumps late (forces the lazy
+    rescale branch) and large logits"""
+    g = torch.Generator().manual_seed(t + d)
+    q = torch.randn(n, t, d, generator=g) * 0.8
+    q[0, 5] *= 6.0          # a key with a huge norm: every query's running maximum jumps when this tile arrives
+    q[0, t - 3] *= 9.0      # ... and again in the last tile
+    vs = [torch.randn(n, t, c, generator=g) for c in cs]
+    att = torch.softmax(q.double() @ q.double().transpose(1, 2), -1)
+    qd = q.to(dev)
+    vds = [v.to(dev) for v in vs]
+    assert FF._fused_attn_ok(qd, vds)
+    res = FF.self_attention(qd, vds)
+    for r, v in zip(res, vs):
+        torch.testing.assert_close(r.cpu().double(), att @ v.double(), rtol=1e-4, atol=2e-5)
+    # and the unfused composition agrees with the fused kernel
+    FF.FUSED_ATTENTION = False
+    try:
+        res2 = FF.self_attention(qd, vds)
+    finally:
+        FF.FUSED_ATTENTION = True
+    for a, b in zip(res, res2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5)
