@@ -48,6 +48,7 @@ SIGNATURES = {
     "fmi_softmax_rows_f32": [vp, vp, i64, i32, vp],
     "fmi_softmax_rows_bwd_f32": [vp, vp, vp, i64, i32, vp],
     "fmi_attention_fwd_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "fmi_attention_bwd_f32": [vp] * 12 + [i32] * 5 + [vp],
     "fmi_eltwise_f32": [i32, vp, vp, vp, i64, f32, vp],
     "fmi_axpy_dev_f32": [vp, vp, vp, vp, i64, vp],
     "fmi_dot_f32": [vp, vp, i64, f32, vp, vp],

@@ -183,3 +183,267 @@ extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const floa
 #undef ATT_LAUNCH
   return fmi_launch_status();
 }
+
+// =====================================================================================================
+// Backward.  With P = softmax(q q^T), O_i = P V_i, upstream gO_i:
+//   dV = P^T gO      dP = gO V^T      dS = P o (dP - delta),  delta_q = sum_c gO[q][c] O[q][c]
+//   dQ[q] += sum_key dS[q][key] q[key]   (query side)       dQ[key] += sum_q dS[q][key] q[q]   (key side; K = Q)
+// One workgroup owns a block of 32 KEYS (dV and the key-side dQ of those keys stay in registers for the whole kernel)
+// and streams all query tiles; P is recomputed from the saved log-sum-exp.  The four waves of the workgroup split the
+// REDUCTION dimensions of the two tile products that feed the softmax backward -- S over d, dP over the value
+// channels -- and exchange their 32x32 partial tiles through LDS, so no product is computed twice:
+//   per (32 queries x 32 keys) pair and wave:  S part 8 + dP part 32 + dV (own 64 channels) 32 + dK or dQ tile 16 MFMAs.
+// Scores are computed with the key on the lane, so P and dS are directly the B operands of the dV / dK products; only
+// the query-side product needs dS transposed, through a private 4 KB LDS tile.  The query-side dQ tiles are added with
+// fp32 atomics (whole 128-byte rows per wave instruction).
+// =====================================================================================================
+template <int D, int NCT>  // NCT = (C1 + C2) / 32, multiple of 4
+__global__ void __launch_bounds__(256, 1) attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ v1,
+                                                          const float* __restrict__ v2, const float* __restrict__ g1,
+                                                          const float* __restrict__ g2, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, float* __restrict__ gv1,
+                                                          float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+  constexpr int CT = NCT * 32, CW = CT / 4, NCW = CW / 32, DW = D / 4;
+  constexpr int LDV = CT + 1, LDQ = D + 1;
+  constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
+  constexpr int NDT = D / 32;  // 32-wide d tiles (1 or 2)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vj = smem;                   // [32][LDV]
+  float* Kj = Vj + 32 * LDV;          // [32][LDQ]
+  float* dOi = Kj + 32 * LDQ;         // [32][LDV]
+  float* Qi = dOi + 32 * LDV;         // [32][LDQ]
+  float* lse_i = Qi + 32 * LDQ;       // [32]
+  float* del_i = lse_i + 32;          // [32]
+  float* EX = del_i + 32;             // [4][2][16][64]
+  float* dsT = EX + 4 * 2 * 1024;     // [2][32][33]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.y, j0 = blockIdx.x * 32;
+  const float* qb = q + (int64_t)n * T * D;
+  const float* v1b = v1 + (int64_t)n * T * C1;
+  const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
+  const float* g1b = g1 + (int64_t)n * T * C1;
+  const float* g2b = g2 ? g2 + (int64_t)n * T * C2 : nullptr;
+  const float* lseb = lse + (int64_t)n * T;
+  const float* delb = delta + (int64_t)n * T;
+
+  // resident key block: V_j, K_j (row-major, odd pitch: conflict-free both along a row and down a column)
+  for (int f = tid; f < 8 * CT; f += 256) {
+    const int key = f / (CT / 4), c = (f % (CT / 4)) * 4;
+    const float4 v = (c < C1) ? *reinterpret_cast<const float4*>(v1b + (int64_t)(j0 + key) * C1 + c)
+                              : *reinterpret_cast<const float4*>(v2b + (int64_t)(j0 + key) * C2 + (c - C1));
+    float* d = Vj + key * LDV + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  for (int f = tid; f < 8 * D; f += 256) {
+    const int key = f / (D / 4), dd = (f % (D / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(qb + (int64_t)(j0 + key) * D + dd);
+    float* d = Kj + key * LDQ + dd;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+
+  f32x16 acc_dv[NCW], acc_dk;
+#pragma unroll
+  for (int c = 0; c < NCW; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dv[c][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_dk[r] = 0.f;
+  const int cbase = wid * CW;            // this wave's value-channel slice
+  const int dbase = wid * DW;            // this wave's d slice of the score product
+  const bool dk_role = wid < NDT;        // waves 0..NDT-1: key-side tile wid;  waves 2..2+NDT-1: query-side tile wid-2
+  const bool dq_role = wid >= 2 && wid - 2 < NDT;
+  const int dt = dk_role ? wid : wid - 2;
+
+  float4 rq[NQL], rg[NVL];
+  float rl = 0.f, rd = 0.f;
+  auto gload = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (D / 4), dd = (f % (D / 4)) * 4;
+      rq[i] = (f < 8 * D) ? *reinterpret_cast<const float4*>(qb + (int64_t)(i0 + row) * D + dd) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (CT / 4), c = (f % (CT / 4)) * 4;
+      rg[i] = (c < C1) ? *reinterpret_cast<const float4*>(g1b + (int64_t)(i0 + row) * C1 + c)
+                       : *reinterpret_cast<const float4*>(g2b + (int64_t)(i0 + row) * C2 + (c - C1));
+    }
+    rl = lseb[i0 + (tid & 31)];
+    rd = delb[i0 + (tid & 31)];
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      if (f < 8 * D) {
+        float* d = Qi + (f / (D / 4)) * LDQ + (f % (D / 4)) * 4;
+        d[0] = rq[i].x; d[1] = rq[i].y; d[2] = rq[i].z; d[3] = rq[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      float* d = dOi + (f / (CT / 4)) * LDV + (f % (CT / 4)) * 4;
+      d[0] = rg[i].x; d[1] = rg[i].y; d[2] = rg[i].z; d[3] = rg[i].w;
+    }
+    if (tid < 32) {
+      lse_i[tid] = rl;
+      del_i[tid] = rd;
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int i0 = 0; i0 < T; i0 += 32) {
+    gload(i0 + 32 < T ? i0 + 32 : i0);  // unconditional prefetch of the next query tile into registers
+    // ---- 1. partial score / dP tiles over this wave's slice of the reduction dimension; lane = key, registers = queries
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sp[r] = 0.f;
+      dp[r] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < DW / 2; ++s)
+      sp = __builtin_amdgcn_mfma_f32_32x32x2f32(Qi[l31 * LDQ + dbase + 2 * s + lh], Kj[l31 * LDQ + dbase + 2 * s + lh], sp, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < CW / 2; ++s)
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dOi[l31 * LDV + cbase + 2 * s + lh], Vj[l31 * LDV + cbase + 2 * s + lh], dp, 0, 0, 0);
+    // ---- 2. exchange: every wave needs the full S and dP tiles
+    {
+      float* ex = EX + wid * 2048 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ex[r * 64] = sp[r];
+        ex[1024 + r * 64] = dp[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += EX[w * 2048 + r * 64 + lane];
+        b += EX[w * 2048 + 1024 + r * 64 + lane];
+      }
+      sp[r] = a;
+      dp[r] = b;
+    }
+    // ---- 3. P and dS (register r of half lh is query (r&3) + 8*(r>>2) + 4*lh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float p = __expf(sp[r] - lse_i[qi]);
+      sp[r] = p;
+      dp[r] = p * (dp[r] - del_i[qi]);
+    }
+    // ---- 4. dV^T[c][key] += gO^T[c][q] P[q][key] for this wave's channels
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int qi = (s & 3) + 8 * (s >> 2) + 4 * lh;
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+        acc_dv[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(dOi[qi * LDV + cbase + c * 32 + l31], sp[s], acc_dv[c], 0, 0, 0);
+    }
+    // ---- 5. key side (dK^T[d][key] += Q^T[d][q] dS[q][key]) or query side (dQ[q][d] = dS[q][key] K[key][d])
+    if (dk_role) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int qi = (s & 3) + 8 * (s >> 2) + 4 * lh;
+        acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qi[qi * LDQ + dt * 32 + l31], dp[s], acc_dk, 0, 0, 0);
+      }
+    } else if (dq_role) {
+      float* t = dsT + (wid - 2) * (32 * 33);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = dp[r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote it; LDS operations of a wave complete in order
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(t[l31 * 33 + 2 * s + lh], Kj[(2 * s + lh) * LDQ + dt * 32 + l31], dq, 0, 0, 0);
+      float* gqb = gq + ((int64_t)n * T + i0) * D + dt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(gqb + (int64_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * D, dq[r]);
+    }
+    __syncthreads();   // all reads of the current query tile are done
+    lstore();
+    __syncthreads();
+  }
+
+  // ---- epilogue: dV rows (plain stores, this workgroup is their only writer) and the key-side dQ (atomics)
+  {
+    const int64_t row = (int64_t)n * T + j0 + l31;
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) {
+      const int ch = cbase + c * 32;
+      float* ob = (ch < C1) ? gv1 + row * C1 + ch : gv2 + row * C2 + (ch - C1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(ob + 8 * g + 4 * lh) =
+            make_float4(acc_dv[c][4 * g], acc_dv[c][4 * g + 1], acc_dv[c][4 * g + 2], acc_dv[c][4 * g + 3]);
+    }
+    if (dk_role) {
+      float* gqb = gq + row * D + dt * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(gqb + (r & 3) + 8 * (r >> 2) + 4 * lh, acc_dk[r]);
+    }
+  }
+}
+
+// delta[row] = sum_c a1[row][c] b1[row][c] (+ second pair): one wave per row
+__global__ void __launch_bounds__(256) rowdot2_kernel(const float* __restrict__ a1, const float* __restrict__ b1, int C1,
+                                                      const float* __restrict__ a2, const float* __restrict__ b2, int C2,
+                                                      float* __restrict__ out, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C1; c += 64) s += a1[row * C1 + c] * b1[row * C1 + c];
+  if (a2)
+    for (int c = lane; c < C2; c += 64) s += a2[row * C2 + c] * b2[row * C2 + c];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const float* v2, const float* o1, const float* o2,
+                                     const float* go1, const float* go2, const float* lse, float* delta_scratch, float* gv1,
+                                     float* gv2, float* gq_zeroed, int N, int T, int D, int C1, int C2, void* stream) {
+  if (!q || !v1 || !o1 || !go1 || !lse || !delta_scratch || !gv1 || !gq_zeroed || N <= 0 || T <= 0 || C1 <= 0 || C2 < 0)
+    return FMI_ERR_BAD_ARG;
+  if (C2 > 0 && (!v2 || !o2 || !go2 || !gv2)) return FMI_ERR_BAD_ARG;
+  if (T % 32 != 0 || C1 % 32 != 0 || C2 % 32 != 0 || N > 65535) return FMI_ERR_UNSUPPORTED;
+  if ((((uintptr_t)q | (uintptr_t)v1 | (uintptr_t)v2 | (uintptr_t)go1 | (uintptr_t)go2 | (uintptr_t)gv1 | (uintptr_t)gv2) & 15) != 0)
+    return FMI_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)N * T;
+  hipLaunchKernelGGL(rowdot2_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, go1, o1, C1, C2 ? go2 : nullptr, o2, C2,
+                     delta_scratch, rows);
+  const int nct = (C1 + C2) / 32;
+  const dim3 grid(T / 32, N), block(256);
+  auto lds_bytes = [](int d, int ct) { return sizeof(float) * (size_t)(2 * 32 * (ct + 1) + 2 * 32 * (d + 1) + 64 + 4 * 2 * 1024 + 2 * 32 * 33); };
+#define ATTB_LAUNCH(DD, NN)                                                                                              \
+  do {                                                                                                                   \
+    static bool attr_set = false; /* > 64 KB of dynamic LDS must be opted into once per kernel */                         \
+    if (!attr_set) {                                                                                                     \
+      if (hipFuncSetAttribute((const void*)attn_bwd_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                              (int)lds_bytes(DD, NN * 32)) != hipSuccess)                                                \
+        return FMI_ERR_LAUNCH;                                                                                           \
+      attr_set = true;                                                                                                   \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd_kernel<DD, NN>), grid, block, lds_bytes(DD, NN * 32), st, q, v1, v2, go1, go2, lse,      \
+                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+  } while (0)
+  if (D == 64 && nct == 8) ATTB_LAUNCH(64, 8);
+  else if (D == 32 && nct == 8) ATTB_LAUNCH(32, 8);
+  else if (D == 32 && nct == 4) ATTB_LAUNCH(32, 4);
+  else if (D == 64 && nct == 4) ATTB_LAUNCH(64, 4);
+  else return FMI_ERR_UNSUPPORTED;
+#undef ATTB_LAUNCH
+  return fmi_launch_status();
+}

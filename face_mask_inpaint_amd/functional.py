@@ -641,7 +641,7 @@ class _SelfAttention(torch.autograd.Function):
                 _L().attention_fwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if len(vs) > 1 else None, _p(outs[0]),
                                        _p(outs[1]) if len(vs) > 1 else None, _p(lse), n, t, d, c1, c2, _st())
             ctx.save_for_backward(q, *vs)
-            ctx.lse = lse
+            ctx.lse, ctx.outs = lse, outs
             return tuple(outs)
         ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES)
         buf = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
@@ -662,6 +662,21 @@ class _SelfAttention(torch.autograd.Function):
     def backward(ctx, *gos):
         q, *vs = ctx.saved_tensors
         n, t, d = q.shape
+        lse = getattr(ctx, "lse", None)
+        csum = sum(v.shape[2] for v in vs)
+        if lse is not None and FUSED_ATTENTION and (d, csum // 32) in ((64, 8), (32, 8), (32, 4), (64, 4)) and all(g is not None for g in gos):
+            gos = [g.contiguous() for g in gos]
+            gq = torch.zeros_like(q)
+            gvs = [torch.empty_like(v) for v in vs]
+            delta = torch.empty((n, t), device=q.device, dtype=torch.float32)
+            c1 = vs[0].shape[2]
+            c2 = vs[1].shape[2] if len(vs) > 1 else 0
+            two = len(vs) > 1
+            with _prof(f"attn_fused_bwd|T{t} d{d} C{c1 + c2} b{n}", 2.0 * n * t * t * (3 * d + 2 * (c1 + c2))):
+                _L().attention_bwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if two else None, _p(ctx.outs[0]), _p(ctx.outs[1]) if two else None,
+                                       _p(gos[0]), _p(gos[1]) if two else None, _p(lse), _p(delta), _p(gvs[0]), _p(gvs[1]) if two else None,
+                                       _p(gq), n, t, d, c1, c2, _st())
+            return (gq,) + tuple(gvs)
         ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES // 2)
         P = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         dP = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)

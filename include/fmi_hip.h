@@ -141,6 +141,12 @@ int fmi_softmax_rows_bwd_f32(const float* p, const float* dp, float* ds, int64_t
 int fmi_attention_fwd_f32(const float* q, const float* v1, const float* v2, float* o1, float* o2, float* lse,
                           int N, int T, int D, int C1, int C2, void* stream);
 
+/* Backward of fmi_attention_fwd_f32 (P recomputed from lse): gv1/gv2 [N,T,C] overwritten, gq_zeroed [N,T,D] accumulated with
+ * fp32 atomics (caller zeroes it), delta_scratch [N,T] workspace.  Supported: T % 32 == 0, D in {32,64}, (C1+C2)/32 in {4,8}. */
+int fmi_attention_bwd_f32(const float* q, const float* v1, const float* v2, const float* o1, const float* o2,
+                          const float* go1, const float* go2, const float* lse, float* delta_scratch,
+                          float* gv1, float* gv2, float* gq_zeroed, int N, int T, int D, int C1, int C2, void* stream);
+
 /* ------------------------------------------------------------------------
  * Bandwidth-class element-wise kernels (float4 vectorised).
  * ---------------------------------------------------------------------- */

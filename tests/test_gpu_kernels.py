@@ -295,7 +295,8 @@ def test_softmax_rows(dev, FF):
         torch.testing.assert_close(dpd.cpu(), ds, rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("n,t,d,cs", [(2, 64, 8, (16, 16)), (1, 300, 16, (32,)), (2, 1024, 32, (128, 128))])
+@pytest.mark.parametrize("n,t,d,cs", [(2, 64, 8, (16, 16)), (1, 300, 16, (32,)), (2, 1024, 32, (128, 128)), (1, 256, 64, (256,)),
+                                      (2, 128, 32, (128,)), (1, 384, 64, (64, 64))])
 def test_self_attention(dev, FF, n, t, d, cs, monkeypatch):
     """softmax(q q^T) v, forward and backward, including the multi-chunk path"""
     monkeypatch.setattr(FF, "ATTN_CHUNK_BYTES", t * 4 * 128 * 2)  # force several query chunks and image groups
