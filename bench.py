@@ -112,6 +112,24 @@ def cpu_baseline(size, seconds_budget=30.0):
     og = torch.optim.Adam(O.unique_trainable(PG), lr=LR)
     od = torch.optim.Adam(O.unique_trainable(PD), lr=LR)
     src, ref, gt, mask, eps_p, eps_q = O.synthetic_batch(1, size, seed=1234, feat_hw=size // 8, z_nc=128)
+    # parity of the generated image on the same weights / inputs: HIP path vs this CPU path (before any update)
+    parity = None
+    if torch.cuda.is_available():
+        import copy
+
+        from face_mask_inpaint_amd import functional as FF
+        from face_mask_inpaint_amd.modules.evaluations.ssim import ssim as ssim_hip
+
+        dev = torch.device("cuda", torch.cuda.current_device())
+        Gd = copy.deepcopy(G).to(dev)
+        with torch.no_grad():
+            got = Gd(src.to(dev), ref.to(dev), src_mask=FF.binarise_mask(mask.to(dev)), eps=(eps_p.to(dev), eps_q.to(dev)))
+            want = O.reference_fill_forward(O.prepare_params(G.state_dict()), src, ref, O.binarise_mask(mask), eps_p, eps_q, out_size=(size, size))
+            wd = want.to(dev).contiguous()
+            parity = {"ssim_vs_cpu": round(float(ssim_hip(got.contiguous(), wd)), 6),
+                      "max_abs_err": float((got - wd).abs().max()), "max_rel_to_range": float((got - wd).abs().max() / wd.abs().max()),
+                      "mask_bit_exact": bool(torch.equal(FF.binarise_mask(mask.to(dev)).cpu(), O.binarise_mask(mask)))}
+        del Gd
     times = []
     t_all = time.time()
     for it in range(6):
@@ -122,7 +140,7 @@ def cpu_baseline(size, seconds_budget=30.0):
             break
     timed = times[1:] if len(times) > 1 else times
     sec = sorted(timed)[len(timed) // 2]
-    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port", "parity": parity,
             "sample": "oracle/picnet_cpu.py train_step at %dx%d, bs=1 (path has no batch-coupled op), 1 warm-up + %d timed steps, median" % (size, size, len(timed))}
 
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "fmi_instnorm_bwd_apply_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_reduce_loss_f32": [i32, vp, vp, i64, f32, f32, vp, vp],
     "fmi_reduce_loss_bwd_f32": [i32, vp, vp, i64, f32, f32, vp, vp, vp],
+    "fmi_ssim_f32": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "fmi_cx_channel_mean_f32": [vp, vp, i64, i32, vp],
     "fmi_cx_normalise_f32": [vp, vp, vp, vp, i64, i32, vp],
     "fmi_cx_normalise_bwd_f32": [vp, vp, vp, vp, i64, i32, vp],

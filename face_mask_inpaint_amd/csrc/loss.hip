@@ -290,3 +290,53 @@ extern "C" int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* a
                      gscale, dcos, N, P, h, scale);
   return fmi_launch_status();
 }
+
+// ---- SSIM (modules/evaluations/ssim.py:18-38): 11x11 gaussian window (outer product of g[ws]), zero padding,
+// per (plane, pixel) ssim value summed into out[plane_group] with fp64 block sums.  Metric only (no gradient).
+__global__ void __launch_bounds__(256) ssim_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ g, int ws, int H, int W, int planes_per_out,
+                                                   float* __restrict__ out) {
+  __shared__ double red[4];
+  __shared__ float sg[64];
+  if (threadIdx.x < ws) sg[threadIdx.x] = g[threadIdx.x];
+  __syncthreads();
+  const int plane = blockIdx.y, half = ws / 2;
+  const float* pa = a + (int64_t)plane * H * W;
+  const float* pb = b + (int64_t)plane * H * W;
+  double acc = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+    const int y = i / W, x = i - y * W;
+    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int dy = 0; dy < ws; ++dy) {
+      const int yy = y + dy - half;
+      if ((unsigned)yy >= (unsigned)H) continue;
+      for (int dx = 0; dx < ws; ++dx) {
+        const int xx = x + dx - half;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const float wgt = sg[dy] * sg[dx];
+        const float va = pa[yy * W + xx], vb = pb[yy * W + xx];
+        m1 += wgt * va;
+        m2 += wgt * vb;
+        s11 += wgt * va * va;
+        s22 += wgt * vb * vb;
+        s12 += wgt * va * vb;
+      }
+    }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+    acc += (double)(((2.f * m12 + C1) * (2.f * (s12 - m12) + C2)) / ((m11 + m22 + C1) * ((s11 - m11) + (s22 - m22) + C2)));
+  }
+  acc = block_sum_256_d(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out + plane / planes_per_out, (float)acc);
+}
+extern "C" int fmi_ssim_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W,
+                            int planes_per_out, float* out_zeroed, void* stream) {
+  if (!img1 || !img2 || !window1d || !out_zeroed || ws <= 0 || ws > 63 || planes <= 0 || H <= 0 || W <= 0 || planes_per_out <= 0 ||
+      planes > 65535)
+    return FMI_ERR_BAD_ARG;
+  int gx = (H * W + 255) / 256;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(ssim_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, img1, img2, window1d, ws, H, W,
+                     planes_per_out, out_zeroed);
+  return fmi_launch_status();
+}

@@ -230,6 +230,11 @@ int fmi_reduce_loss_bwd_f32(int kind, const float* a, const float* b, int64_t n,
                             const float* gscale, float* ga, void* stream);
 
 
+/* SSIM metric (modules/evaluations/ssim.py:18-38): NCHW planes, window = outer product of window1d[ws], zero padding;
+ * out[plane / planes_per_out] += sum over the plane's pixels of the ssim map (caller zeroes out and divides). */
+int fmi_ssim_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W,
+                 int planes_per_out, float* out_zeroed, void* stream);
+
 /* ------------------------------------------------------------------------
  * Contextual loss (external_function.py:231-274), x,y NHWC features [N,P,C].
  * ---------------------------------------------------------------------- */

@@ -329,3 +329,20 @@ if __name__ == "__main__":
     picnet_op_fixtures()
     picnet_train_fixture()
     stylegan2_fixtures()
+
+
+def ssim_fixture():
+    """modules/evaluations/ssim.py is torch-only and imports as is."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from modules.evaluations import ssim as R
+
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(2, 3, 40, 37, generator=g)
+    b = (a + 0.1 * torch.randn(2, 3, 40, 37, generator=g)).clamp(0, 1)
+    torch.save({"a": a, "b": b, "mean": R.ssim(a, b), "per_image": R.ssim(a, b, size_average=False), "same": R.ssim(a, a)},
+               os.path.join(OUT, "ssim.pt"))
+
+
+if __name__ == "__main__":
+    ssim_fixture()

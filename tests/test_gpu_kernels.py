@@ -454,3 +454,14 @@ def test_fused_attention_forward(dev, FF, n, t, d, cs):
         FF.FUSED_ATTENTION = True
     for a, b in zip(res, res2):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5)
+
+
+def test_ssim_metric(dev, golden):
+    """modules/evaluations/ssim.py mirror against the reference's own outputs"""
+    from face_mask_inpaint_amd.modules.evaluations.ssim import SSIM, ssim
+
+    fx = golden("ssim.pt")
+    a, b = fx["a"].to(dev), fx["b"].to(dev)
+    torch.testing.assert_close(ssim(a, b).cpu(), fx["mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ssim(a, b, size_average=False).cpu(), fx["per_image"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(SSIM()(a, a).cpu(), fx["same"], rtol=1e-5, atol=1e-6)

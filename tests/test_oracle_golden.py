@@ -161,3 +161,12 @@ def test_stylegan2_blocks_oracle(golden):
     f = fx["torgb"]
     P = {"m." + k: v.clone() for k, v in f["sd"].items() if v.dtype.is_floating_point}
     torch.testing.assert_close(S.to_rgb(P, "m", f["x"], f["style"], f["skip"]), f["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_ssim_oracle(golden):
+    from oracle import ssim_cpu as S
+
+    fx = golden("ssim.pt")
+    torch.testing.assert_close(S.ssim(fx["a"], fx["b"]), fx["mean"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(S.ssim(fx["a"], fx["b"], size_average=False), fx["per_image"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(S.ssim(fx["a"], fx["a"]), fx["same"], rtol=1e-5, atol=1e-6)
