@@ -219,14 +219,22 @@ def main():
             with open(args.profile_dump, "w") as fh:
                 for k, v in sorted(detail.items(), key=lambda kv: -kv[1][1]):
                     fh.write("%9.3f ms %4d launches %7.1f TFLOP/s  %s\n" % (v[1], v[2], v[0] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0, k))
-        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:6]
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        top = sorted(by.items(), key=lambda kv: -kv[1][1])
+        fam = tot_fl / (tot_ms * 1e-3) / 1e12
+        dom_key, (dom_fl, dom_ms, dom_n) = sorted(detail.items(), key=lambda kv: -kv[1][1])[0]  # one kernel at one shape
+        dom_tag = dom_key.split("|")[0]
+        ach = dom_fl / (dom_ms * 1e-3) / 1e12
+        kernel_names = {"attn_fused_bwd": "attn_bwd_kernel<64,8> (csrc/attention.hip: fused softmax(QQ^T)V backward, fp32 MFMA)",
+                        "attn_fused_fwd": "attn_fwd_kernel<64,8> (csrc/attention.hip)"}
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_mfma_f32_kernel (fp32 v_mfma_f32_32x32x2 implicit-GEMM family: conv fwd/adjoint/wgrad, attention, gram)",
-                    "launches": len(recs), "kernel_ms_per_step": round(tot_ms, 2), "algorithmic_tflop_per_step": round(tot_fl / 1e12, 3),
+                    "kernel": kernel_names.get(dom_tag, "gemm_mfma_f32_kernel<...> call site " + dom_tag), "shape": dom_key.split("|")[-1],
+                    "launches_per_step": dom_n, "avg_launch_ms": round(dom_ms / dom_n, 3),
+                    "algorithmic_tflop_per_launch": round(dom_fl / dom_n / 1e12, 4),
+                    "mfma_family": {"achieved": round(fam, 2), "frac": round(fam / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(recs),
+                                    "kernel_ms_per_step": round(tot_ms, 2), "algorithmic_tflop_per_step": round(tot_fl / 1e12, 3)},
                     "by_call_site": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None, "ms": round(v[1], 2), "launches": v[2]}
-                                     for k, v in top}}
+                                     for k, v in top[:7]}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -40,7 +40,7 @@ SIGNATURES = {
     "fmi_gemm_f32": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64, i64, f32, f32, vp, vp],
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],
-    "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, i32, i64, vp],
+    "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, vp, i32, i64, vp],
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_weight_prepare_f32": [vp, i32, vp],

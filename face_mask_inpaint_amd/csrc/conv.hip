@@ -87,19 +87,23 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
   return FMI_OK;
 }
 
-extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, int batch_w,
-                                    int64_t w_bstride, void* stream) {
+extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
+                                    int batch_w, int64_t w_bstride, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !dy || !dwf || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
-  const int Mg = g.Kdim(), Ng = d->K, Kg = g.Mdim();
-  WgradAX la{x, g};
+  // the bias gradient rides along as one extra output row (needs a float4-aligned row index and shared weights)
+  const bool fuse_bias = dbias && batch_w == 1 && (g.Kdim() % 4 == 0);
+  if (dbias && !fuse_bias) return FMI_ERR_UNSUPPORTED;
+  const int ones_row = fuse_bias ? g.Kdim() : -1;
+  const int Mg = g.Kdim() + (fuse_bias ? 1 : 0), Ng = d->K, Kg = g.Mdim();
+  WgradAX la{x, g, ones_row};
   DenseX lb{dy, (int64_t)d->y_cstride, (int64_t)d->OH * d->OW * d->y_cstride, Ng, Kg,
             (d->K % 4 == 0) && (d->y_cstride % 4 == 0) && aligned16(dy)};
-  WgradEp ep{dwf, g, d->K, w_bstride};
+  WgradEp ep{dwf, g, d->K, w_bstride, dbias, ones_row};
   // split the (long) pixel reduction over workgroups; partial sums meet through fp32 atomics
   const int64_t tiles = ceil_div64(Mg, 128) * ceil_div64(Ng, Ng <= 32 ? 32 : (Ng <= 64 ? 64 : 128));
   int64_t ksplit = 2048 / (tiles * batch_w);

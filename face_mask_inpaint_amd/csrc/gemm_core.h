@@ -216,6 +216,8 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
   static constexpr bool KMODE = false;
   const float* p;
   ConvGeom g;
+  int ones_row;  // >= 0: one extra row of ones after the (tap, channel) rows, so that the SAME product also yields the
+                 // bias gradient sum_pixels dy[p][k] as an extra output row (no separate reduction pass over dy)
   struct Ctx {  // cached (tap, channel) of the first of the four rows a thread stages
     int t0, c0;
   };
@@ -240,6 +242,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
   __device__ float4 load4(const Ctx& cx, int x, int k) const {
     const int t0 = cx.t0, c0 = cx.c0;
     if (k >= g.Mdim()) return zero4();
+    if (x == ones_row) return make_float4(1.f, 0.f, 0.f, 0.f);  // ones_row is a multiple of 4 whenever it is enabled
     const uint32_t n = fdiv((uint32_t)k, g.dG);
     const uint32_t rem = (uint32_t)k - n * (uint32_t)(g.GH * g.GW);
     const uint32_t gy = fdiv(rem, g.dGW);
@@ -322,14 +325,20 @@ struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 at
   ConvGeom g;
   int Kout;
   int64_t bs;
+  float* dbias;   // target of the extra ones-row (may be null)
+  int ones_row;
   __device__ void set_batch(int b) { dw += (int64_t)b * bs; }
   __device__ int64_t row_off(int row) const {
+    if (row == ones_row) return -1;
     const int t = (int)fdiv((uint32_t)row, g.dC);
     const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
     const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
     return ((int64_t)wtap * g.C + (row - t * g.C)) * Kout;
   }
-  __device__ void store(int64_t off, int col, float v) const { atomicAdd(dw + off + col, v); }
+  __device__ void store(int64_t off, int col, float v) const {
+    if (off < 0) atomicAdd(dbias + col, v);
+    else atomicAdd(dw + off + col, v);
+  }
 };
 
 #ifndef FMI_HOST_EMU

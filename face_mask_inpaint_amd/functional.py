@@ -246,9 +246,13 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
             gwf = torch.zeros_like(wf)
+            want_gb = ctx.has[0] and ctx.needs_input_grad[2]
+            fuse = want_gb and (kh * kw * c) % 4 == 0
+            if fuse:
+                gb = torch.zeros(k, device=x.device, dtype=torch.float32)
             with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
-                lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), 1, 0, _st())
-        if ctx.has[0] and ctx.needs_input_grad[2]:
+                lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), _p(gb) if fuse else None, 1, 0, _st())
+        if ctx.has[0] and ctx.needs_input_grad[2] and gb is None:
             gb = torch.zeros(k, device=x.device, dtype=torch.float32)
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
@@ -300,7 +304,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gwf = torch.zeros_like(wf)
             with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
-                lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), 1, 0, _st())
+                lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
             gb = torch.zeros(cb, device=x.device, dtype=torch.float32)
             lib.bias_grad_f32(_p(gy), gy.numel() // cb, cb, cb, _p(gb), _st())

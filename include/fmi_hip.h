@@ -86,8 +86,10 @@ int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, 
  * fmi_reflect_pad_fold_f32). */
 int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
                          const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream);
-/* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf. */
-int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf,
+/* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf.
+ * dbias (may be NULL; needs kh*kw*C % 4 == 0 and batch_w == 1): dbias[k] += sum over pixels dy[p][k], computed by the same
+ * GEMM as one extra row of ones -- no separate pass over dy; caller zeroes it. */
+int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
                          int batch_w, int64_t w_bstride, void* stream);
 /* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
 int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);

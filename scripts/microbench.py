@@ -23,7 +23,7 @@ def conv_case(n, h, c, k, ks=3, stride=1, pad=1):
     st = FF._st()
     timeit(lambda: lib.conv2d_fwd_f32(C.byref(d), FF._p(x), FF._p(w), None, None, FF._p(y), 0, 1, 0, st), fl, f"conv_fwd   n{n} {h}x{h} {c}->{k} k{ks}s{stride}")
     timeit(lambda: lib.conv2d_dgrad_f32(C.byref(d), FF._p(gy), FF._p(wt), None, None, FF._p(dx), 1, 0, st), fl, f"conv_dgrad n{n} {h}x{h} {c}->{k} k{ks}s{stride}")
-    timeit(lambda: lib.conv2d_wgrad_f32(C.byref(d), FF._p(x), FF._p(gy), FF._p(dw), 1, 0, st), fl, f"conv_wgrad n{n} {h}x{h} {c}->{k} k{ks}s{stride}")
+    timeit(lambda: lib.conv2d_wgrad_f32(C.byref(d), FF._p(x), FF._p(gy), FF._p(dw), None, 1, 0, st), fl, f"conv_wgrad n{n} {h}x{h} {c}->{k} k{ks}s{stride}")
 
 def gemm_case(m, n, k, b, ta, tb, name):
     a = torch.randn(b, k, m, device=dev) if ta else torch.randn(b, m, k, device=dev)

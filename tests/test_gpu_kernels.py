@@ -113,11 +113,16 @@ def test_conv_family(dev, FF, n, c, k, h, w, ksz, stride, pad):
     lib.conv2d_dgrad_f32(C.byref(d), FF._p(gyh), FF._p(wtp), None, None, FF._p(dx), 1, 0, st)
     torch.testing.assert_close(dx.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
     dwf = torch.zeros_like(wf)
-    lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf), 1, 0, st)
+    lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf), None, 1, 0, st)
     torch.testing.assert_close(dwf.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=2e-4)
     db = torch.zeros(k, device=dev)
     lib.bias_grad_f32(FF._p(gyh), n * oh * ow, k, k, FF._p(db), st)
     torch.testing.assert_close(db.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+    if (ksz * ksz * c) % 4 == 0:  # fused: the bias gradient is an extra row of the weight-gradient GEMM
+        dwf2, db2 = torch.zeros_like(wf), torch.zeros(k, device=dev)
+        lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf2), FF._p(db2), 1, 0, st)
+        torch.testing.assert_close(dwf2.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=2e-4)
+        torch.testing.assert_close(db2.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
 
 
 def test_conv_transpose_and_autograd(dev, FF):

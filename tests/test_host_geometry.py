@@ -77,8 +77,13 @@ def test_conv_fwd_dgrad_wgrad(emu, n, c, k, h, w, ksz, stride, pad):
     emu.conv2d_dgrad_f32(C.byref(d), ptr(gyh), ptr(wtp), None, None, ptr(dx), 1, 0, None)
     torch.testing.assert_close(dx, nhwc(x.grad), rtol=1e-5, atol=1e-5)
     dwf = torch.zeros_like(wf)
-    emu.conv2d_wgrad_f32(C.byref(d), ptr(xh), ptr(gyh), ptr(dwf), 1, 0, None)
+    emu.conv2d_wgrad_f32(C.byref(d), ptr(xh), ptr(gyh), ptr(dwf), None, 1, 0, None)
     torch.testing.assert_close(dwf, pack(wt_.grad)[0], rtol=1e-4, atol=1e-4)
+    if (ksz * ksz * c) % 4 == 0:  # bias gradient as an extra row of ones in the same product
+        dwf2, db = torch.zeros_like(wf), torch.zeros(k)
+        emu.conv2d_wgrad_f32(C.byref(d), ptr(xh), ptr(gyh), ptr(dwf2), ptr(db), 1, 0, None)
+        torch.testing.assert_close(dwf2, dwf, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(db, gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
 
 
 def test_conv_transpose_is_the_adjoint(emu):
@@ -103,7 +108,7 @@ def test_conv_transpose_is_the_adjoint(emu):
     emu.conv2d_fwd_f32(C.byref(d), ptr(gyh), ptr(wf), None, None, ptr(gx), 0, 1, 0, None)
     torch.testing.assert_close(gx, nhwc(x.grad), rtol=1e-5, atol=1e-5)
     dwf = torch.zeros_like(wf)
-    emu.conv2d_wgrad_f32(C.byref(d), ptr(gyh), ptr(xh), ptr(dwf), 1, 0, None)
+    emu.conv2d_wgrad_f32(C.byref(d), ptr(gyh), ptr(xh), ptr(dwf), None, 1, 0, None)
     torch.testing.assert_close(dwf, pack(w.grad)[0], rtol=1e-4, atol=1e-4)
 
 
