@@ -27,6 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+# HBM-side bytes per launch of the dominant kernel, from the rocprofv3 PMC passes committed under profiles/
+# (round1_pmc_attention.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as the guide
+# prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE counts the fp32 atomics of the dQ tiles exactly).
+PMC_TRAFFIC_BYTES = {"attn_fused_bwd|T16384 d64 C256 b8": 2 * 1397544.1 * 1024 + 17039360.0 * 1024,
+                     "attn_fused_fwd|T16384 d64 C256 b8": 2 * 670658.9 * 1024 + 131584.0 * 1024}
 ENC = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
 DEC = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
 DISC = dict(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
@@ -160,12 +165,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    if os.environ.get("FMI_REHEARSAL_ONE_GPU"):  # 2-rank rehearsal of the multi-process path on a one-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl")  # RCCL over xGMI
+        dist.init_process_group("gloo" if os.environ.get("FMI_REHEARSAL_ONE_GPU") else "nccl")  # "nccl" = RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from face_mask_inpaint_amd import functional as FF
@@ -227,7 +234,8 @@ def main():
         kernel_names = {"attn_fused_bwd": "attn_bwd_kernel<64,8> (csrc/attention.hip: fused softmax(QQ^T)V backward, fp32 MFMA)",
                         "attn_fused_fwd": "attn_fwd_kernel<64,8> (csrc/attention.hip)"}
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dom_key),
+                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/round1_pmc_attention.json)",
                     "kernel": kernel_names.get(dom_tag, "gemm_mfma_f32_kernel<...> call site " + dom_tag), "shape": dom_key.split("|")[-1],
                     "launches_per_step": dom_n, "avg_launch_ms": round(dom_ms / dom_n, 3),
                     "algorithmic_tflop_per_launch": round(dom_fl / dom_n / 1e12, 4),
