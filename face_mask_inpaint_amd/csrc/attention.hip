@@ -396,6 +396,189 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(const float* __restric
   }
 }
 
+// =====================================================================================================
+// Backward, second structure (used when it fits): every wave owns its OWN block of 32 keys with ALL value channels and
+// keeps that key block's V and K fragments in registers (the lane-constant B operands of the score and dP products), so
+//  * nothing is exchanged between waves before the softmax backward (the first structure above exchanges partial tiles),
+//  * one query tile staged in LDS feeds four key blocks (4x fewer L2 reads of gO / Q),
+//  * the query-side dQ tiles of the four key blocks are summed through LDS first: 4x fewer fp32 atomics
+//    (rocprofv3 WRITE_SIZE showed 17 GB of atomic traffic per launch for the first structure at T = 16384).
+// One wave per SIMD, ~420 of the 512 registers; 352 MFMAs per wave between barriers.
+// =====================================================================================================
+template <int D, int NCT>
+__global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restrict__ q, const float* __restrict__ v1,
+                                                           const float* __restrict__ v2, const float* __restrict__ g1,
+                                                           const float* __restrict__ g2, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, float* __restrict__ gv1,
+                                                           float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+  constexpr int CT = NCT * 32, LDV = CT + 1, LDQ = D + 1, NDT = D / 32;
+  constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dOi = smem;                   // [32][LDV]  query tile of the upstream gradient
+  float* Qi = dOi + 32 * LDV;          // [32][LDQ]
+  float* lse_i = Qi + 32 * LDQ;        // [32]
+  float* del_i = lse_i + 32;           // [32]
+  float* Kw = del_i + 32;              // [4][32][LDQ]   each wave's key block (B operand of the query-side product)
+  float* dsT = Kw + 4 * 32 * LDQ;      // [4][32][33]    private transposed dS tiles
+  float* RB = dsT + 4 * 32 * 33;       // [4][NDT][16][64] query-side partial tiles, summed over the four key blocks
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.y, j0 = blockIdx.x * 128 + wid * 32;   // this wave's keys
+  const float* qb = q + (int64_t)n * T * D;
+  const float* v1b = v1 + (int64_t)n * T * C1;
+  const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
+  const float* g1b = g1 + (int64_t)n * T * C1;
+  const float* g2b = g2 ? g2 + (int64_t)n * T * C2 : nullptr;
+  const float* lseb = lse + (int64_t)n * T;
+  const float* delb = delta + (int64_t)n * T;
+
+  float* kw = Kw + wid * 32 * LDQ;
+  for (int f = lane; f < 8 * D; f += 64) {
+    const int key = f / (D / 4), dd = (f % (D / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(qb + (int64_t)(j0 + key) * D + dd);
+    float* d = kw + key * LDQ + dd;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  float kfrag[D / 2], vfrag[CT / 2];   // K[key = l31][2s + lh], V[key = l31][2s + lh]
+#pragma unroll
+  for (int s = 0; s < D / 2; ++s) kfrag[s] = qb[(int64_t)(j0 + l31) * D + 2 * s + lh];
+#pragma unroll
+  for (int s = 0; s < CT / 2; ++s) {
+    const int c = 2 * s + lh;
+    vfrag[s] = (c < C1) ? v1b[(int64_t)(j0 + l31) * C1 + c] : v2b[(int64_t)(j0 + l31) * C2 + (c - C1)];
+  }
+
+  f32x16 acc_dv[NCT], acc_dk[NDT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dv[c][r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NDT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dk[c][r] = 0.f;
+
+  float4 rq[NQL], rg[NVL];
+  float rl = 0.f, rd = 0.f;
+  auto gload = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (D / 4), dd = (f % (D / 4)) * 4;
+      rq[i] = (f < 8 * D) ? *reinterpret_cast<const float4*>(qb + (int64_t)(i0 + row) * D + dd) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (CT / 4), c = (f % (CT / 4)) * 4;
+      rg[i] = (c < C1) ? *reinterpret_cast<const float4*>(g1b + (int64_t)(i0 + row) * C1 + c)
+                       : *reinterpret_cast<const float4*>(g2b + (int64_t)(i0 + row) * C2 + (c - C1));
+    }
+    rl = lseb[i0 + (tid & 31)];
+    rd = delb[i0 + (tid & 31)];
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      if (f < 8 * D) {
+        float* d = Qi + (f / (D / 4)) * LDQ + (f % (D / 4)) * 4;
+        d[0] = rq[i].x; d[1] = rq[i].y; d[2] = rq[i].z; d[3] = rq[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      float* d = dOi + (f / (CT / 4)) * LDV + (f % (CT / 4)) * 4;
+      d[0] = rg[i].x; d[1] = rg[i].y; d[2] = rg[i].z; d[3] = rg[i].w;
+    }
+    if (tid < 32) {
+      lse_i[tid] = rl;
+      del_i[tid] = rd;
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  float* t = dsT + wid * (32 * 33);
+  for (int i0 = 0; i0 < T; i0 += 32) {
+    gload(i0 + 32 < T ? i0 + 32 : i0);
+    // ---- S[q][key], dP[q][key]: lane = key, registers = queries
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sp[r] = 0.f;
+      dp[r] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) sp = __builtin_amdgcn_mfma_f32_32x32x2f32(Qi[l31 * LDQ + 2 * s + lh], kfrag[s], sp, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < CT / 2; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dOi[l31 * LDV + 2 * s + lh], vfrag[s], dp, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float p = __expf(sp[r] - lse_i[qi]);
+      sp[r] = p;
+      dp[r] = p * (dp[r] - del_i[qi]);
+    }
+    // ---- dV^T[c][key] += gO^T[c][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int qi = (s & 3) + 8 * (s >> 2) + 4 * lh;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) acc_dv[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(dOi[qi * LDV + c * 32 + l31], sp[s], acc_dv[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) acc_dk[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qi[qi * LDQ + c * 32 + l31], dp[s], acc_dk[c], 0, 0, 0);
+    }
+    // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys, through the private transposed tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = dp[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NDT; ++c) {
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(t[l31 * 33 + 2 * s + lh], kw[(2 * s + lh) * LDQ + c * 32 + l31], dq, 0, 0, 0);
+      float* rb = RB + ((wid * NDT + c) * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rb[r * 64] = dq[r];
+    }
+    __syncthreads();   // every wave is done with the query tile; RB holds the four partial dQ tiles
+    // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
+#pragma unroll
+    for (int rr = 0; rr < NDT * 4; ++rr) {
+      const int row = wid * NDT * 4 + rr;       // = c*16 + r
+      const int c = row >> 4, r = row & 15;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += RB[((w * NDT + c) * 16 + r) * 64 + lane];
+      atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, s);
+    }
+    lstore();
+    __syncthreads();
+  }
+
+  // ---- epilogue: dV rows of this wave's keys (plain stores) and the key-side dQ (atomics)
+  const int64_t row = (int64_t)n * T + j0 + l31;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int ch = c * 32;
+    float* ob = (ch < C1) ? gv1 + row * C1 + ch : gv2 + row * C2 + (ch - C1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(ob + 8 * g + 4 * lh) = make_float4(acc_dv[c][4 * g], acc_dv[c][4 * g + 1], acc_dv[c][4 * g + 2], acc_dv[c][4 * g + 3]);
+  }
+#pragma unroll
+  for (int c = 0; c < NDT; ++c) {
+    float* gqb = gq + row * D + c * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(gqb + (r & 3) + 8 * (r >> 2) + 4 * lh, acc_dk[c][r]);
+  }
+}
+
 // delta[row] = sum_c a1[row][c] b1[row][c] (+ second pair): one wave per row
 __global__ void __launch_bounds__(256) rowdot2_kernel(const float* __restrict__ a1, const float* __restrict__ b1, int C1,
                                                       const float* __restrict__ a2, const float* __restrict__ b2, int C2,
@@ -425,7 +608,32 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
   hipLaunchKernelGGL(rowdot2_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, go1, o1, C1, C2 ? go2 : nullptr, o2, C2,
                      delta_scratch, rows);
   const int nct = (C1 + C2) / 32;
-  const dim3 grid(T / 32, N), block(256);
+  const dim3 block(256);
+  if (T % 128 == 0) {  // second structure: one key block per wave, fragments in registers, 4x fewer atomics
+    const dim3 grid2(T / 128, N);
+    auto lds2 = [](int d, int ct) {
+      return sizeof(float) * (size_t)(32 * (ct + 1) + 32 * (d + 1) + 64 + 4 * 32 * (d + 1) + 4 * 32 * 33 + 4 * (d / 32) * 16 * 64);
+    };
+#define ATTB2_LAUNCH(DD, NN)                                                                                             \
+  do {                                                                                                                   \
+    static bool attr_set2 = false;                                                                                       \
+    if (!attr_set2) {                                                                                                    \
+      if (hipFuncSetAttribute((const void*)attn_bwd2_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              (int)lds2(DD, NN * 32)) != hipSuccess)                                                     \
+        return FMI_ERR_LAUNCH;                                                                                           \
+      attr_set2 = true;                                                                                                  \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse,         \
+                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+    return fmi_launch_status();                                                                                          \
+  } while (0)
+    if (D == 64 && nct == 8) ATTB2_LAUNCH(64, 8);
+    if (D == 32 && nct == 8) ATTB2_LAUNCH(32, 8);
+    if (D == 32 && nct == 4) ATTB2_LAUNCH(32, 4);
+    if (D == 64 && nct == 4) ATTB2_LAUNCH(64, 4);
+#undef ATTB2_LAUNCH
+  }
+  const dim3 grid(T / 32, N);
   auto lds_bytes = [](int d, int ct) { return sizeof(float) * (size_t)(2 * 32 * (ct + 1) + 2 * 32 * (d + 1) + 64 + 4 * 2 * 1024 + 2 * 32 * 33); };
 #define ATTB_LAUNCH(DD, NN)                                                                                              \
   do {                                                                                                                   \
@@ -447,3 +655,4 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
 #undef ATTB_LAUNCH
   return fmi_launch_status();
 }
+
