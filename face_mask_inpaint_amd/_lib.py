@@ -87,6 +87,9 @@ SIGNATURES = {
     "fmi_sqsum_last_bwd_f32": [vp, vp, vp, i64, i32, vp],
     "fmi_noise_bias_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     "fmi_upfirdn2d_nhwc_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_prelu_f32": [vp, vp, vp, i64, i32, vp],
+    "fmi_prelu_bwd_f32": [vp, vp, vp, vp, vp, i64, i32, vp],
+    "fmi_subsample_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_bias_grad_nchw_f32": [vp, i32, i32, i64, vp, vp],
     "fmi_noise_bias_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
 }

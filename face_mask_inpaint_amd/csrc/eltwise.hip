@@ -20,11 +20,13 @@ __device__ __forceinline__ float ew_op(float a, float b, float p0) {
   if (OP == FMI_EW_SUB) return a - b;
   if (OP == FMI_EW_RSQRT) return 1.f / sqrtf(a + p0);
   if (OP == FMI_EW_RSQRT_BWD) return -0.5f * a * b * b * b;
+  if (OP == FMI_EW_SIGMOID) return 1.f / (1.f + expf(-a));
+  if (OP == FMI_EW_SIGMOID_BWD) return a * b * (1.f - b);
   return 0.f;
 }
 template <int OP>
 constexpr bool ew_binary() {
-  return !(OP == FMI_EW_LRELU || OP == FMI_EW_SCALE || OP == FMI_EW_SOFTPLUS || OP == FMI_EW_RSQRT);
+  return !(OP == FMI_EW_LRELU || OP == FMI_EW_SCALE || OP == FMI_EW_SOFTPLUS || OP == FMI_EW_RSQRT || OP == FMI_EW_SIGMOID);
 }
 
 template <int OP, bool VEC>
@@ -79,6 +81,8 @@ extern "C" int fmi_eltwise_f32(int op, const float* a, const float* b, float* y,
     case FMI_EW_SUB: return launch_ew<FMI_EW_SUB>(a, b, y, n, p0, st);
     case FMI_EW_RSQRT: return launch_ew<FMI_EW_RSQRT>(a, b, y, n, p0, st);
     case FMI_EW_RSQRT_BWD: return launch_ew<FMI_EW_RSQRT_BWD>(a, b, y, n, p0, st);
+    case FMI_EW_SIGMOID: return launch_ew<FMI_EW_SIGMOID>(a, b, y, n, p0, st);
+    case FMI_EW_SIGMOID_BWD: return launch_ew<FMI_EW_SIGMOID_BWD>(a, b, y, n, p0, st);
     default: return FMI_ERR_UNSUPPORTED;
   }
 }

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) in_finalize_kernel(const double* __restri
 
 static int check_c(int C) {
   const int cg = C / 4;
-  if (C % 4 != 0 || cg < 1 || cg > 256 || (cg & (cg - 1)) != 0) return FMI_ERR_UNSUPPORTED;  // CG must divide 256
+  if (C % 4 != 0 || cg < 1 || cg > 256) return FMI_ERR_UNSUPPORTED;  // one thread per 4-channel group; 256 % CG lanes idle
   return FMI_OK;
 }
 

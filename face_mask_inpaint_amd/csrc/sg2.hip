@@ -148,3 +148,85 @@ extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, floa
                      in_w, C, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, total);
   return fmi_launch_status();
 }
+
+// ---- pSp encoder helpers (modules/psp/encoders/helpers.py): PReLU(C), MaxPool2d(1, stride) ------------------------
+// y = x > 0 ? x : a[c] * x
+__global__ void __launch_bounds__(256) prelu_kernel(const float* __restrict__ x, const float* __restrict__ a, float* __restrict__ y,
+                                                    int64_t total, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : a[i % C] * v;
+  }
+}
+extern "C" int fmi_prelu_f32(const float* x, const float* a, float* y, int64_t rows, int C, void* stream) {
+  if (!x || !a || !y || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = rows * C;
+  hipLaunchKernelGGL(prelu_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, a, y, total, C);
+  return fmi_launch_status();
+}
+// gx = g * (x > 0 ? 1 : a[c]);  ga[c] += sum_rows g * x * (x <= 0)   (caller zeroes ga)
+__global__ void __launch_bounds__(256) prelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                        const float* __restrict__ a, float* __restrict__ gx, float* __restrict__ ga,
+                                                        int64_t rows, int C, int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int cg = 0; cg < C; cg += 64) {
+    const int c = cg + tx;
+    float s = 0.f;
+    if (c < C) {
+      const float ac = a[c];
+      for (int64_t r = r0 + ty; r < r1; r += 4) {
+        const float xv = x[r * C + c], gv = g[r * C + c];
+        gx[r * C + c] = xv > 0.f ? gv : ac * gv;
+        if (xv <= 0.f) s += gv * xv;
+      }
+    }
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(ga + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    __syncthreads();
+  }
+}
+extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, int64_t rows, int C,
+                                 void* stream) {
+  if (!g || !x || !a || !gx || !ga || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  int64_t blocks = ceil_div64(rows, 128);
+  if (blocks > 2048) blocks = 2048;
+  const int64_t rpb = ceil_div64(rows, blocks);
+  blocks = ceil_div64(rows, rpb);
+  hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, x, a, gx, ga, rows, C, rpb);
+  return fmi_launch_status();
+}
+// y[n][oy][ox][c] = x[n][oy*s][ox*s][c]  (MaxPool2d(kernel 1, stride s)); backward scatters into a zero-filled gx
+__global__ void __launch_bounds__(256) subsample_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                        int OH, int OW, int s, int64_t total, int backward) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    if (!backward) {  // i indexes y
+      const int ox = (int)(r % OW);
+      r /= OW;
+      const int oy = (int)(r % OH);
+      const int64_t n = r / OH;
+      y[i] = x[((n * H + (int64_t)oy * s) * W + (int64_t)ox * s) * C + c];
+    } else {          // i indexes gx (= y argument), x argument = gy
+      const int xx = (int)(r % W);
+      r /= W;
+      const int yy = (int)(r % H);
+      const int64_t n = r / H;
+      const bool hit = (yy % s == 0) && (xx % s == 0) && (yy / s < OH) && (xx / s < OW);
+      y[i] = hit ? x[((n * OH + yy / s) * OW + xx / s) * C + c] : 0.f;
+    }
+  }
+}
+extern "C" int fmi_subsample_f32(const float* x, float* y, int N, int H, int W, int C, int stride, int backward, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0) return FMI_ERR_BAD_ARG;
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int64_t total = backward ? (int64_t)N * H * W * C : (int64_t)N * OH * OW * C;
+  hipLaunchKernelGGL(subsample_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, OH, OW, stride,
+                     total, backward);
+  return fmi_launch_status();
+}

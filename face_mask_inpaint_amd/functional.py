@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, FmiError
 
-EW_LRELU, EW_LRELU_BWD, EW_TANH_BWD, EW_ADD, EW_SCALE, EW_AXPY, EW_MUL, EW_RELU_BWD_OUT, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_SUB, EW_RSQRT, EW_RSQRT_BWD = range(13)
+EW_LRELU, EW_LRELU_BWD, EW_TANH_BWD, EW_ADD, EW_SCALE, EW_AXPY, EW_MUL, EW_RELU_BWD_OUT, EW_SOFTPLUS, EW_SOFTPLUS_BWD, EW_SUB, EW_RSQRT, EW_RSQRT_BWD, EW_SIGMOID, EW_SIGMOID_BWD = range(15)
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 
 # scratch budget for one attention score chunk (kept well inside the 256 MB Infinity Cache)
@@ -1049,6 +1049,132 @@ class _UpFirDnNHWC(torch.autograd.Function):
 
 def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0)):
     return _UpFirDnNHWC.apply(x, kernel.contiguous(), int(up), int(down), (int(pad[0]), int(pad[1])))
+
+
+# ---------------------------------------------------------------------------------------------------
+# pSp encoder pieces (modules/psp/encoders/helpers.py)
+# ---------------------------------------------------------------------------------------------------
+class _Sigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = eltwise(EW_SIGMOID, x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return eltwise(EW_SIGMOID_BWD, g.contiguous(), y)
+
+
+def sigmoid(x):
+    return _Sigmoid.apply(x)
+
+
+class _PReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        _chk(x, a)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _L().prelu_f32(_p(x), _p(a), _p(y), x.numel() // c, c, _st())
+        ctx.save_for_backward(x, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a = ctx.saved_tensors
+        c = x.shape[-1]
+        gx, ga = torch.empty_like(x), torch.zeros_like(a)
+        _L().prelu_bwd_f32(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), x.numel() // c, c, _st())
+        return gx, ga
+
+
+def prelu(x, a):
+    """nn.PReLU(C) on an NHWC tensor"""
+    return _PReLU.apply(x, a)
+
+
+class _Subsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        _chk(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, (h - 1) // stride + 1, (w - 1) // stride + 1, c), device=x.device, dtype=torch.float32)
+        _L().subsample_f32(_p(x), _p(y), n, h, w, c, stride, 0, _st())
+        ctx.cfg = (x.shape, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (n, h, w, c), stride = ctx.cfg
+        gx = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
+        _L().subsample_f32(_p(g.contiguous()), _p(gx), n, h, w, c, stride, 1, _st())
+        return gx, None
+
+
+def subsample(x, stride):
+    """nn.MaxPool2d(1, stride)"""
+    return x if stride == 1 else _Subsample.apply(x, stride)
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    """BatchNorm2d (training statistics) on NHWC: statistics over (N, H, W) per channel = the instance-norm kernels with the
+    batch folded into the pixel axis.  Returns (y, stats[C][2] = (mean, rstd))."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _chk(x, gamma, beta)
+        lib = _L()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        sums = torch.zeros((1, c, 2), device=x.device, dtype=torch.float64)
+        stats = torch.empty((1, c, 2), device=x.device, dtype=torch.float32)
+        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), 1, rows, c, eps, _st())
+        y = torch.empty_like(x)
+        lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), 1, rows, c, 1.0, _st())
+        ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, g, _gstats):
+        lib = _L()
+        x, stats, gamma, beta = ctx.saved_tensors
+        c = x.shape[-1]
+        rows = x.numel() // c
+        g = g.contiguous()
+        red = torch.zeros((1, c, 2), device=x.device, dtype=torch.float64)
+        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), 1, rows, c, 1.0, _st())
+        gx, dg, db = torch.empty_like(x), torch.zeros_like(gamma), torch.zeros_like(beta)
+        lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
+                                   1, rows, c, 1.0, _st())
+        return gx, dg, db, None
+
+
+def batch_norm_train(x, gamma, beta, eps=1e-5):
+    return _BatchNormTrain.apply(x, gamma, beta, float(eps))
+
+
+def channel_affine(x, scale, shift):
+    """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); scale/shift are plain (no-grad) tensors"""
+    n = x.shape[0]
+    c = x.shape[-1]
+    y = scale_channels(x.reshape(1, -1, c), scale.view(1, c).contiguous())
+    return _BiasAdd.apply(y.view(x.shape), shift.contiguous())
+
+
+class _BiasAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b):
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _L().noise_bias_act_f32(_p(x), _p(b), None, None, _p(y), x.numel() // c, c, 1.0, 1.0, _st())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,128 @@
+"""Host-side mirror of modules/psp/encoders/helpers.py (get_blocks, SEModule, bottleneck_IR, bottleneck_IR_SE) with the
+reference's parameter names (``res_layer.N.*``, ``shortcut_layer.N.*``, ``fc1/fc2``); forward runs on the HIP kernels in
+NHWC.  BatchNorm2d uses batch statistics in training mode (running statistics are updated like torch does) and the
+running statistics in eval mode."""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+from torch.nn import AdaptiveAvgPool2d, BatchNorm2d, Conv2d, MaxPool2d, Module, PReLU, ReLU, Sequential, Sigmoid
+
+from .... import functional as FF
+from ....weights import weight_scope
+from ...pluralistic_model.external_function import run_conv
+
+
+class Flatten(Module):
+    def forward(self, input):
+        return input.view(input.size(0), -1)
+
+
+class Bottleneck(namedtuple("Block", ["in_channel", "depth", "stride"])):
+    """A named tuple describing a ResNet block."""
+
+
+def get_block(in_channel, depth, num_units, stride=2):
+    return [Bottleneck(in_channel, depth, stride)] + [Bottleneck(depth, depth, 1) for _ in range(num_units - 1)]
+
+
+def get_blocks(num_layers):
+    units = {50: (3, 4, 14, 3), 100: (3, 13, 30, 3), 152: (3, 8, 36, 3)}
+    if num_layers not in units:
+        raise ValueError("Invalid number of layers: {}. Must be one of [50, 100, 152]".format(num_layers))
+    u = units[num_layers]
+    return [get_block(64, 64, u[0]), get_block(64, 128, u[1]), get_block(128, 256, u[2]), get_block(256, 512, u[3])]
+
+
+def batch_norm(bn: BatchNorm2d, x):
+    """nn.BatchNorm2d forward on NHWC with torch's training / eval semantics"""
+    if bn.training or not bn.track_running_stats:
+        y, stats = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():  # running-statistics bookkeeping on [C] vectors
+                cnt = x.numel() // x.shape[-1]
+                mean = stats[0, :, 0]
+                var = (1.0 / stats[0, :, 1] ** 2 - bn.eps) * (cnt / max(cnt - 1, 1))
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var, alpha=m)
+                bn.num_batches_tracked += 1
+        return y
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias - bn.running_mean * scale
+    return FF.channel_affine(x, scale, shift)
+
+
+class SEModule(Module):
+    def __init__(self, channels, reduction):
+        super().__init__()
+        self.avg_pool = AdaptiveAvgPool2d(1)
+        self.fc1 = Conv2d(channels, channels // reduction, kernel_size=1, padding=0, bias=False)
+        self.relu = ReLU(inplace=True)
+        self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
+        self.sigmoid = Sigmoid()
+
+    def nhwc(self, x):
+        with weight_scope(self):
+            n, h, w, c = x.shape
+            if h != w:
+                raise NotImplementedError("SEModule: square feature maps only")
+            s = FF.avg_pool(x, h)                                  # [N,1,1,C]
+            s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
+            s = FF.sigmoid(run_conv(self.fc2, s))
+            return FF.scale_channels(x, s.view(n, c))
+
+    def forward(self, x):
+        return FF.to_nchw(self.nhwc(FF.to_nhwc(x)))
+
+
+class _Bottleneck(Module):
+    def nhwc(self, x):
+        with weight_scope(self):
+            if isinstance(self.shortcut_layer, MaxPool2d):
+                sc = FF.subsample(x, self._stride)
+            else:
+                sc = batch_norm(self.shortcut_layer[1], run_conv(self.shortcut_layer[0], x))
+            r = batch_norm(self.res_layer[0], x)
+            r = run_conv(self.res_layer[1], r)
+            r = FF.prelu(r, self.res_layer[2].weight)
+            r = run_conv(self.res_layer[3], r)
+            r = batch_norm(self.res_layer[4], r)
+            if len(self.res_layer) > 5:
+                r = self.res_layer[5].nhwc(r)
+            return FF.add(r, sc)
+
+    def forward(self, x):
+        return FF.to_nchw(self.nhwc(FF.to_nhwc(x)))
+
+
+def _layers(in_channel, depth, stride, se):
+    res = [BatchNorm2d(in_channel), Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False), PReLU(depth),
+           Conv2d(depth, depth, (3, 3), stride, 1, bias=False), BatchNorm2d(depth)]
+    if se:
+        res.append(SEModule(depth, 16))
+    return Sequential(*res)
+
+
+class bottleneck_IR(_Bottleneck):
+    def __init__(self, in_channel, depth, stride):
+        super().__init__()
+        self._stride = stride
+        if in_channel == depth:
+            self.shortcut_layer = MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = Sequential(Conv2d(in_channel, depth, (1, 1), stride, bias=False), BatchNorm2d(depth))
+        self.res_layer = _layers(in_channel, depth, stride, se=False)
+
+
+class bottleneck_IR_SE(_Bottleneck):
+    def __init__(self, in_channel, depth, stride):
+        super().__init__()
+        self._stride = stride
+        if in_channel == depth:
+            self.shortcut_layer = MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = Sequential(Conv2d(in_channel, depth, (1, 1), stride, bias=False), BatchNorm2d(depth))
+        self.res_layer = _layers(in_channel, depth, stride, se=True)

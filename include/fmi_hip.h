@@ -166,6 +166,8 @@ enum {
   FMI_EW_SUB = 10,         /* y = a - b */
   FMI_EW_RSQRT = 11,       /* y = rsqrt(a + p0) */
   FMI_EW_RSQRT_BWD = 12,   /* y = -0.5 * a * b^3          a = grad, b = forward output */
+  FMI_EW_SIGMOID = 13,     /* y = 1 / (1 + exp(-a)) */
+  FMI_EW_SIGMOID_BWD = 14, /* y = a * b * (1 - b)         b = forward output */
   FMI_EW_COUNT_
 };
 int fmi_eltwise_f32(int op, const float* a, const float* b, float* y, int64_t n, float p0, void* stream);
@@ -297,6 +299,12 @@ int fmi_noise_bias_act_bwd_f32(const float* g, const float* y, const float* nois
 int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int N, int in_h, int in_w, int C,
                            int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                            int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* pSp encoder helpers (modules/psp/encoders/helpers.py:56-119), NHWC rows x C */
+int fmi_prelu_f32(const float* x, const float* a, float* y, int64_t rows, int C, void* stream);                 /* nn.PReLU(C) */
+int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga_zeroed, int64_t rows, int C, void* stream);
+/* MaxPool2d(1, stride) = sub-sampling; backward != 0: x is the output gradient [N,OH,OW,C], y the (fully written) input gradient */
+int fmi_subsample_f32(const float* x, float* y, int N, int H, int W, int C, int stride, int backward, void* stream);
 
 #ifdef __cplusplus
 }

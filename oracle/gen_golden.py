@@ -346,3 +346,133 @@ def ssim_fixture():
 
 if __name__ == "__main__":
     ssim_fixture()
+
+
+def psp_fixtures():
+    """IR-SE bottlenecks, GradualStyleBlock, the GradualStyleEncoder forward (its 512-channel IR-50 body would be a
+    170 MB fixture, so the reference's own ``forward`` is run on an instance assembled from the reference's own block
+    classes at reduced widths: same 24-block body, same taps 6/20/23) and pSpLoss with the LPIPS / ID lambdas at 0."""
+    import torch.utils.cpp_extension as cpp_ext
+    from torch import nn
+
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    install_torchvision_stub()
+    cpp_ext.load = lambda *a, **k: None
+    import modules.psp.stylegan2.op  # noqa: F401
+    from modules.psp.encoders import helpers as H
+    from modules.psp.encoders import psp_encoders as E
+    from modules.psp import criteria as CR
+    from modules.example_guided_att import ExampleGuidedAttention
+
+    g = torch.Generator().manual_seed(33)
+    fx = {}
+
+    def randomise(m):
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if p.ndim == 1:
+                    p.copy_(torch.rand(p.shape, generator=g) * 0.5 + (0.1 if "2.weight" in n or n.endswith("bias") else 0.75))
+            for n, b in m.named_buffers():
+                if n.endswith("running_mean"):
+                    b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+                elif n.endswith("running_var"):
+                    b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+    def block_case(name, m, x_shape):
+        randomise(m)
+        sd0 = sd_clone(m)
+        x = torch.randn(*x_shape, generator=g, requires_grad=True)
+        m.train()
+        y = m(x)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        sd1 = sd_clone(m)
+        m.eval()
+        with torch.no_grad():
+            ye = m(x)
+        fx[name] = dict(sd=sd0, x=x.detach(), out=y.detach(), gout=gy, gx=x.grad.clone(),
+                        gparams={n: p.grad.clone() for n, p in m.named_parameters()},
+                        stats_after={k: v for k, v in sd1.items() if "running" in k or "num_batches" in k}, out_eval=ye)
+
+    torch.manual_seed(17)
+    block_case("ir_se_conv_s2", H.bottleneck_IR_SE(16, 32, 2), (3, 16, 12, 12))
+    block_case("ir_se_pool_s1", H.bottleneck_IR_SE(32, 32, 1), (2, 32, 9, 9))
+    block_case("ir_se_pool_s2", H.bottleneck_IR_SE(32, 32, 2), (2, 32, 10, 10))
+    block_case("ir_conv_s2", H.bottleneck_IR(8, 24, 2), (2, 8, 11, 11))
+    block_case("style_block", E.GradualStyleBlock(16, 16, 8), (3, 16, 8, 8))
+
+    # --- encoder forward at reduced widths -----------------------------------------------------------------------
+    widths = (8, 16, 16, 32, 32)
+    spatial = (4, 8, 16)
+    n_styles = 10
+    enc = E.GradualStyleEncoder.__new__(E.GradualStyleEncoder)
+    nn.Module.__init__(enc)
+    w0, w1, w2, w3, w4 = widths
+    enc.input_layer = nn.Sequential(nn.Conv2d(3, w0, (3, 3), 1, 1, bias=False), nn.BatchNorm2d(w0), nn.PReLU(w0))
+    sc = {64: w1, 128: w2, 256: w3, 512: w4}
+    mods = []
+    for i, block in enumerate(H.get_blocks(50)):
+        for j, b in enumerate(block):
+            mods.append(H.bottleneck_IR_SE(w0 if i == 0 and j == 0 else sc[b.in_channel], sc[b.depth], b.stride))
+    enc.body = nn.Sequential(*mods)
+    enc.styles = nn.ModuleList()
+    enc.style_count, enc.coarse_ind, enc.middle_ind = n_styles, 3, 7
+    for i in range(n_styles):
+        enc.styles.append(E.GradualStyleBlock(w4, w4, spatial[0] if i < 3 else (spatial[1] if i < 7 else spatial[2])))
+    enc.latlayer1 = nn.Conv2d(w3, w4, 1)
+    enc.latlayer2 = nn.Conv2d(w2, w4, 1)
+    enc.use_attention = True
+    enc.attention1 = ExampleGuidedAttention(w4, out_channels=w4)
+    enc.attention2 = ExampleGuidedAttention(w3, out_channels=w3)
+    randomise(enc)
+    sd0 = sd_clone(enc)
+    x = torch.randn(2, 3, 64, 64, generator=g, requires_grad=True)
+    ref = torch.randn(2, 3, 64, 64, generator=g, requires_grad=True)
+    mask = torch.zeros(2, 64, 64)
+    mask[0, 20:50, 10:40] = 1
+    mask[1, 5:30, 30:60] = 1
+    enc.train()
+    out = enc(x, ref=ref, mask=mask)
+    gy = torch.randn(out.shape, generator=g)
+    out.backward(gy)
+    keep = ("input_layer.0.weight", "input_layer.2.weight", "body.0.shortcut_layer.0.weight", "body.3.res_layer.0.weight", "body.6.res_layer.3.weight",
+            "body.12.res_layer.5.fc2.weight", "body.23.res_layer.4.bias", "styles.0.linear.weight", "styles.5.convs.0.weight",
+            "styles.9.convs.6.bias", "latlayer1.weight", "latlayer2.bias", "attention1.conv.weight", "attention2.out_conv.weight")
+    gp = dict(enc.named_parameters())
+    sd1 = sd_clone(enc)
+    enc.eval()
+    with torch.no_grad():
+        out_eval = enc(x, ref=ref, mask=mask)
+        out_noref = enc(x)
+    enc.use_attention = False
+    with torch.no_grad():
+        out_noatt = enc(x, ref=ref, mask=mask)
+    fx["encoder"] = dict(widths=widths, spatial=spatial, n_styles=n_styles, sd=sd0, x=x.detach(), ref=ref.detach(), mask=mask, out=out.detach(),
+                         gout=gy, gx=x.grad.clone(), gref=ref.grad.clone(), gparams={k: gp[k].grad.clone() for k in keep},
+                         stats_after={k: v for k, v in sd1.items() if "running" in k or "num_batches" in k},
+                         out_eval=out_eval, out_eval_noref=out_noref, out_eval_noatt=out_noatt)
+
+    # --- pSpLoss ---------------------------------------------------------------------------------------------------
+    args = types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0.5, lpips_lambda_ref=0, l2_lambda_ref=0.7,
+                                 cx_lambda=0.1, w_norm_lambda=0.005, start_from_latent_avg=True)
+    torch.manual_seed(3)
+    crit = CR.pSpLoss(args)
+    xs = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    ys = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    rf = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    yh = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).requires_grad_(True)
+    lat = torch.randn(2, 10, 32, generator=g, requires_grad=True)
+    lavg = torch.randn(10, 32, generator=g)
+    loss, ld, _ = crit(xs, ys, yh, lat, latent_avg=lavg, ref=rf, mask=mask)
+    loss.backward()
+    loss_nm, ld_nm, _ = crit(xs, ys, yh.detach(), lat.detach(), latent_avg=None, ref=None, mask=None)
+    fx["psp_loss"] = dict(args={k: float(v) if not isinstance(v, bool) else v for k, v in vars(args).items()}, vgg=sd_clone(crit.vgg_loss), x=xs, y=ys, ref=rf,
+                          y_hat=yh.detach(), latent=lat.detach(), latent_avg=lavg, mask=mask, loss=loss.detach(), loss_dict={k: torch.tensor(v) for k, v in ld.items()},
+                          gy_hat=yh.grad.clone(), glatent=lat.grad.clone(), loss_nomask=loss_nm.detach(), loss_dict_nomask={k: torch.tensor(v) for k, v in ld_nm.items()})
+    torch.save(fx, os.path.join(OUT, "psp_ops.pt"))
+    print("psp_ops:", sorted(fx), "%.1f MB" % (os.path.getsize(os.path.join(OUT, "psp_ops.pt")) / 1e6))
+
+
+if __name__ == "__main__":
+    psp_fixtures()

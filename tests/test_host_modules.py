@@ -84,3 +84,33 @@ def test_initialisation_follows_reference_rule():
     assert float(g.attn1.gamma) == 0.0 and float(g.attn1.alpha) == 0.0
     u = g.decoder0.conv1.module.weight_u
     torch.testing.assert_close(u.norm(), torch.tensor(1.0), rtol=1e-5, atol=1e-6)
+
+
+def test_psp_state_dict_keys_match_reference(golden):
+    """the pSp-side mirrors take the reference's state_dicts unchanged (strict load), and pSp builds offline"""
+    import types
+
+    from face_mask_inpaint_amd.modules.psp.encoders import helpers as H
+    from face_mask_inpaint_amd.modules.psp.encoders.psp_encoders import GradualStyleBlock, GradualStyleEncoder
+    from face_mask_inpaint_amd.modules.psp.psp import get_keys, pSp
+
+    fx = golden("psp_ops.pt")
+    H.bottleneck_IR_SE(16, 32, 2).load_state_dict(fx["ir_se_conv_s2"]["sd"], strict=True)
+    H.bottleneck_IR_SE(32, 32, 2).load_state_dict(fx["ir_se_pool_s2"]["sd"], strict=True)
+    H.bottleneck_IR(8, 24, 2).load_state_dict(fx["ir_conv_s2"]["sd"], strict=True)
+    GradualStyleBlock(16, 16, 8).load_state_dict(fx["style_block"]["sd"], strict=True)
+    e = fx["encoder"]
+    enc = GradualStyleEncoder(50, "ir_se", types.SimpleNamespace(n_styles=e["n_styles"], use_attention=True), _widths=tuple(e["widths"]),
+                              _spatial=tuple(e["spatial"]))
+    enc.load_state_dict(e["sd"], strict=True)
+    assert len(enc.body) == 24 and [b.stride for blk in H.get_blocks(50) for b in blk].count(2) == 4
+    with pytest.raises(ValueError):
+        H.get_blocks(34)
+    assert get_keys({"state_dict": {"encoder.a.b": 1, "decoder.c": 2}}, "encoder") == {"a.b": 1}
+    opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
+                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True)
+    net = pSp(opts)
+    assert opts.n_styles == 14 and len(net.encoder.styles) == 14
+    assert not any(p.requires_grad for p in net.decoder.parameters()) and all(p.requires_grad for p in net.encoder.parameters())
+    with pytest.raises(Exception):
+        pSp(types.SimpleNamespace(**{**vars(opts), "encoder_type": "nope"}))

@@ -170,3 +170,94 @@ def test_ssim_oracle(golden):
     torch.testing.assert_close(S.ssim(fx["a"], fx["b"]), fx["mean"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(S.ssim(fx["a"], fx["b"], size_average=False), fx["per_image"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(S.ssim(fx["a"], fx["a"]), fx["same"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pSp encoder side (rows B1, B9): oracle/psp_cpu.py vs the reference's own modules
+# ---------------------------------------------------------------------------------------------------------------------
+def _psp_params(sd, prefix="b."):
+    P = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+        P[prefix + k] = v
+    return P
+
+
+PSP_BLOCKS = [("ir_se_conv_s2", 2), ("ir_se_pool_s1", 1), ("ir_se_pool_s2", 2), ("ir_conv_s2", 2)]
+
+
+@pytest.mark.parametrize("name,stride", PSP_BLOCKS)
+def test_psp_bottlenecks_oracle(golden, name, stride):
+    from oracle import psp_cpu as PO
+    fx = golden("psp_ops.pt")[name]
+    P = _psp_params(fx["sd"])
+    x = fx["x"].clone().requires_grad_(True)
+    y = PO.bottleneck(P, "b", x, stride, training=True)
+    torch.testing.assert_close(y, fx["out"], rtol=1e-5, atol=2e-6)
+    y.backward(fx["gout"])
+    torch.testing.assert_close(x.grad, fx["gx"], rtol=1e-4, atol=2e-6)
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(P["b." + n].grad, g, rtol=1e-4, atol=1e-4 * float(g.abs().max()) + 1e-7, msg=lambda m, n=n: f"{n}: {m}")
+    for k, v in fx["stats_after"].items():
+        torch.testing.assert_close(P["b." + k], v, rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+    P = _psp_params({**fx["sd"], **fx["stats_after"]})  # the reference's eval pass ran after the training pass
+    with torch.no_grad():
+        torch.testing.assert_close(PO.bottleneck(P, "b", fx["x"], stride, training=False), fx["out_eval"], rtol=1e-5, atol=2e-6)
+
+
+def test_psp_style_block_oracle(golden):
+    from oracle import psp_cpu as PO
+    fx = golden("psp_ops.pt")["style_block"]
+    P = _psp_params(fx["sd"])
+    x = fx["x"].clone().requires_grad_(True)
+    y = PO.gradual_style_block(P, "b", x, 16)
+    torch.testing.assert_close(y, fx["out"], **TOL)
+    y.backward(fx["gout"])
+    torch.testing.assert_close(x.grad, fx["gx"], rtol=1e-4, atol=1e-6)
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(P["b." + n].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
+
+
+def test_psp_encoder_oracle(golden):
+    from oracle import psp_cpu as PO
+    fx = golden("psp_ops.pt")["encoder"]
+    P = _psp_params(fx["sd"], "")
+    x, ref = fx["x"].clone().requires_grad_(True), fx["ref"].clone().requires_grad_(True)
+    out = PO.gradual_style_encoder(P, "", x, ref, fx["mask"], fx["n_styles"], True, True)
+    torch.testing.assert_close(out, fx["out"], rtol=1e-4, atol=1e-5)
+    out.backward(fx["gout"])
+    torch.testing.assert_close(x.grad, fx["gx"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(ref.grad, fx["gref"], rtol=1e-3, atol=1e-5)
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(P[n].grad, g, rtol=1e-3, atol=1e-3 * float(g.abs().max()) + 1e-7, msg=lambda m, n=n: f"{n}: {m}")
+    for k, v in fx["stats_after"].items():
+        torch.testing.assert_close(P[k], v, rtol=1e-5, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+    P = _psp_params({**fx["sd"], **fx["stats_after"]}, "")
+    with torch.no_grad():
+        torch.testing.assert_close(PO.gradual_style_encoder(P, "", fx["x"], fx["ref"], fx["mask"], fx["n_styles"], True, False), fx["out_eval"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(PO.gradual_style_encoder(P, "", fx["x"], None, None, fx["n_styles"], True, False), fx["out_eval_noref"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(PO.gradual_style_encoder(P, "", fx["x"], fx["ref"], fx["mask"], fx["n_styles"], False, False), fx["out_eval_noatt"], rtol=1e-4, atol=1e-5)
+
+
+def test_psp_loss_oracle(golden):
+    from oracle import psp_cpu as PO
+    fx = golden("psp_ops.pt")["psp_loss"]
+    a = fx["args"]
+    yh, lat = fx["y_hat"].clone().requires_grad_(True), fx["latent"].clone().requires_grad_(True)
+    loss = PO.psp_loss(fx["y"], yh, lat, fx["latent_avg"], fx["ref"], fx["mask"], a["l2_lambda"], a["l2_lambda_ref"], a["w_norm_lambda"])
+    torch.testing.assert_close(loss, fx["loss"], **TOL)
+    loss.backward()
+    torch.testing.assert_close(yh.grad, fx["gy_hat"], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(lat.grad, fx["glatent"], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(PO.psp_loss(fx["y"], fx["y_hat"], fx["latent"], None, None, None, a["l2_lambda"], a["l2_lambda_ref"], a["w_norm_lambda"]),
+                               fx["loss_nomask"], **TOL)
+    # the logged-only VGG terms (criteria/__init__.py:74-76,88-90)
+    PV = O.prepare_params({"vgg" + k: v for k, v in fx["vgg"].items()}, frozen=True)
+    m = fx["mask"].unsqueeze(1)
+    with torch.no_grad():
+        st = O.vgg_loss(PV, "vgg", fx["y_hat"] * (1 - m), fx["x"], "style") * a["style_lambda"]
+        cx = O.vgg_loss(PV, "vgg", fx["y_hat"] * m, fx["ref"] * m, "contextual") * a["cx_lambda"]
+    torch.testing.assert_close(st, fx["loss_dict"]["loss_style"].float(), rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(cx, fx["loss_dict"]["loss_context"].float(), rtol=1e-4, atol=1e-7)
