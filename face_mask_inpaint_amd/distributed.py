@@ -59,18 +59,68 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], bucket_bytes: int 
 
 
 class DataParallelOptimizer:
-    """Wraps an optimiser so that ``step()`` first averages the gradients over all ranks.  Drop-in for the
-    ``optimizer_G`` / ``optimizer_D`` arguments of GANOptimizer (loss.py:70)."""
+    """Wraps an optimiser so that ``step()`` applies the gradient averaged over all ranks.  Drop-in for the
+    ``optimizer_G`` / ``optimizer_D`` arguments of GANOptimizer (loss.py:70).
 
-    def __init__(self, optimizer: torch.optim.Optimizer, bucket_bytes: int = 32 << 20):
+    The all-reduce is overlapped with the backward pass: a post-accumulate hook on every parameter appends its finished
+    gradient to the open bucket, and a full bucket is flattened and all-reduced asynchronously (RCCL runs it on the process
+    group's own stream) while autograd keeps producing the earlier layers' gradients.  ``launch()`` sends whatever is still
+    open without blocking -- GANOptimizer uses it to put the discriminator's gradients on the wire before the generator
+    backward (whose first ~20 % is the VGG dgrad, which produces no gradients of its own) starts.  ``step()`` sends the
+    rest, waits, writes the averages back into ``.grad`` and steps.  Bucket membership follows hook order, which is a
+    function of the graph and therefore identical on every rank.  One backward per step (no gradient accumulation)."""
+
+    def __init__(self, optimizer: torch.optim.Optimizer, bucket_bytes: int = 16 << 20, group=None):
         self.optimizer = optimizer
         self.bucket_bytes = bucket_bytes
+        self.group = group
+        self._open: List[torch.nn.Parameter] = []
+        self._open_bytes = 0
+        self._inflight = []  # (work, flat, params)
+        self.collectives = 0
+        self._hooks = []
+        if is_distributed():
+            for g in optimizer.param_groups:
+                for p in g["params"]:
+                    if p.requires_grad:
+                        self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        self._open.append(p)
+        self._open_bytes += p.grad.numel() * p.grad.element_size()
+        if self._open_bytes >= self.bucket_bytes:
+            self.launch()
+
+    def launch(self):
+        """all-reduce the open bucket asynchronously; returns immediately"""
+        if not self._open:
+            return
+        params, self._open, self._open_bytes = self._open, [], 0
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight.append((work, flat, params))
+        self.collectives += 1
+
+    def _finish(self):
+        self.launch()
+        world = dist.get_world_size(self.group)
+        for work, flat, params in self._inflight:
+            work.wait()
+            flat.div_(world)
+            views, off = [], 0
+            for p in params:
+                n = p.grad.numel()
+                views.append(flat[off:off + n].view_as(p.grad))
+                off += n
+            torch._foreach_copy_([p.grad for p in params], views)
+        self._inflight = []
 
     @property
     def param_groups(self):
         return self.optimizer.param_groups
 
     def zero_grad(self, *a, **k):
+        self._open, self._open_bytes = [], 0
         return self.optimizer.zero_grad(*a, **k)
 
     def state_dict(self):
@@ -80,6 +130,9 @@ class DataParallelOptimizer:
         return self.optimizer.load_state_dict(sd)
 
     def step(self, closure=None):
-        params = [p for g in self.optimizer.param_groups for p in g["params"]]
-        allreduce_gradients(params, self.bucket_bytes)
+        if is_distributed():
+            if self._hooks:
+                self._finish()
+            else:  # process group created after this wrapper: plain bucketed all-reduce
+                allreduce_gradients([p for g in self.optimizer.param_groups for p in g["params"]], self.bucket_bytes, self.group)
         return self.optimizer.step(closure)

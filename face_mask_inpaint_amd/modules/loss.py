@@ -140,6 +140,7 @@ class GANOptimizer(nn.Module):
         self.lambda_style = 250
         self.lambda_cx = 1
         self.lambda_g = lambda_g
+        self.early_d = None  # None: automatic (on when the optimisers are DataParallelOptimizer); True / False force it
 
     @staticmethod
     def _masked(img, mask, invert):
@@ -185,6 +186,24 @@ class GANOptimizer(nn.Module):
             (self._masked(gen_img, src_mask, False), self._masked(ref_img, src_mask, False), "contextual")])  # loss.py:91-95
         perc_loss, style_loss, cx_loss = perc * self.lambda_perc, sty * self.lambda_style, cx * self.lambda_cx
         G_loss = G_loss + perc_loss + style_loss + cx_loss
+        early_d = self.early_d if self.early_d is not None else hasattr(self.optimizer_D, "launch")
+        if early_d:
+            # Data-parallel schedule: the discriminator loss depends only on gen_img and on the pre-update D
+            # weights, so its forward (same D call order gen -> gt -> gen.detach(), hence the same SpectralNorm u/v
+            # sequence) and backward run BEFORE the generator backward; the D gradients then travel over xGMI while the
+            # VGG dgrad at the head of G_loss.backward() runs, and the G buckets follow as the decoder/encoder gradients
+            # complete.  Every tensor has the value it has in the reference order (loss.py:120-134).
+            D_loss = self.discriminator_loss(discriminator, gt_img, gen_img)
+            self.optimizer_D.zero_grad()
+            D_loss.backward()
+            launch = getattr(self.optimizer_D, "launch", None)
+            if launch is not None:
+                launch()
+            self.optimizer_G.zero_grad()
+            G_loss.backward()
+            self.optimizer_G.step()
+            self.optimizer_D.step()
+            return D_loss, G_loss, perc_loss, style_loss, cx_loss
         self.optimizer_G.zero_grad()
         G_loss.backward()
         self.optimizer_G.step()

@@ -70,3 +70,62 @@ def test_two_rank_gradient_exchange(tmp_path):
     for k, v in m.state_dict().items():
         torch.testing.assert_close(a[k], v, rtol=1e-5, atol=1e-6)
     assert float(a["unused"]) == 0.0
+
+
+def _gan_worker(rank, world, port, out):
+    """two wrapped optimisers in the early-discriminator order GANOptimizer uses when data-parallel: D backward, D launch()
+    (non-blocking), G backward with hook-driven buckets, G step, D step"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from face_mask_inpaint_amd import distributed as fd
+
+    G, D = _model(), _model()
+    fd.broadcast_parameters([G, D])
+    og = fd.DataParallelOptimizer(torch.optim.Adam(G.parameters(), lr=1e-2), bucket_bytes=200)
+    od = fd.DataParallelOptimizer(torch.optim.Adam(D.parameters(), lr=1e-2), bucket_bytes=1 << 20)  # never fills: needs launch()
+    x, y = _data(rank)
+    for _ in range(2):
+        gen = G(x)
+        for p in D.parameters():  # the generator pass must not produce D gradients (GANOptimizer does the same)
+            p.requires_grad_(False)
+        g_loss = torch.nn.functional.mse_loss(gen, y) + 0.1 * D(torch.cat([gen, gen], 1)).square().mean()
+        for p in D.parameters():
+            p.requires_grad_(True)
+        d_loss = D(torch.cat([gen.detach(), y], 1)).square().mean()
+        od.zero_grad()
+        d_loss.backward()
+        od.launch()
+        assert len(od._inflight) == 1 and not od._open
+        og.zero_grad()
+        g_loss.backward()
+        og.step()
+        od.step()
+    assert og.collectives >= 4 and od.collectives == 2
+    torch.save({"G": G.state_dict(), "D": D.state_dict()}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_two_rank_early_discriminator_schedule(tmp_path):
+    port, out = _free_port(), str(tmp_path / "gan")
+    mp.spawn(_gan_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    for net in ("G", "D"):
+        for k in a[net]:
+            assert torch.equal(a[net][k], b[net][k]), (net, k)
+    # reference order in one process on the union of the shards: G backward, G step, then D loss / backward / step
+    G, D = _model(), _model()
+    og, od = torch.optim.Adam(G.parameters(), lr=1e-2), torch.optim.Adam(D.parameters(), lr=1e-2)
+    data = [_data(0), _data(1)]
+    for _ in range(2):
+        gens = [G(x) for x, _ in data]
+        g_loss = sum(torch.nn.functional.mse_loss(g, y) + 0.1 * D(torch.cat([g, g], 1)).square().mean() for g, (_, y) in zip(gens, data)) / 2
+        og.zero_grad()
+        g_loss.backward()
+        og.step()
+        d_loss = sum(D(torch.cat([g.detach(), y], 1)).square().mean() for g, (_, y) in zip(gens, data)) / 2
+        od.zero_grad()
+        d_loss.backward()
+        od.step()
+    for net, m in (("G", G), ("D", D)):
+        for k, v in m.state_dict().items():
+            torch.testing.assert_close(a[net][k], v, rtol=1e-5, atol=1e-6, msg=lambda s, k=k: f"{net}.{k}: {s}")
