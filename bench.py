@@ -204,6 +204,9 @@ def main():
     assert all(torch.isfinite(l).item() for l in losses), "non-finite loss"
 
     roofline = None
+    if not args.no_roofline and rank != 0:
+        train_step(G, D, gopt, batch)  # the profiled step is a collective step: every rank takes part, rank 0 records
+        torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         FF.PROFILE = []
         train_step(G, D, gopt, batch)

@@ -8,10 +8,14 @@ base_function.py:410-418) are skipped consistently because the set is a function
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
+
+
+_DEBUG = bool(os.environ.get("FMI_DIST_DEBUG"))
 
 
 def is_distributed() -> bool:
@@ -97,6 +101,10 @@ class DataParallelOptimizer:
             return
         params, self._open, self._open_bytes = self._open, [], 0
         flat = torch.cat([p.grad.reshape(-1) for p in params])
+        if _DEBUG:
+            import sys
+            print(f"[fmi.dist r{dist.get_rank()}] bucket #{self.collectives} of {type(self.optimizer).__name__}@{id(self) & 0xffff:x}: "
+                  f"{len(params)} tensors, {flat.numel() * 4} bytes", file=sys.stderr, flush=True)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((work, flat, params))
         self.collectives += 1
