@@ -42,6 +42,10 @@ __host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) 
   return (t + ((n - t) >> f.s1)) >> f.s2;
 }
 
+#ifndef FMI_EXP
+#define FMI_EXP 0  // bit mask of timing experiments (results become wrong): 1 no barrier, 2 no global loads, 4 no LDS stores in the main loop, 8 loads re-read the first tile; 16 = prefetch distance 2 (results stay right)
+#endif
+
 // ---- tile configurations ----
 template <int WM_, int WN_, int TM_, int TN_>
 struct TileCfg {
@@ -84,6 +88,9 @@ struct DenseK {  // reduction index contiguous in memory
     if (k + 3 < K) r.w = q[3];
     return r;
   }
+  // LDS-DMA path: address of the 16-byte chunk (x, k..k+3), nullptr = zeros
+  __host__ __device__ bool dma_ok() const { return vec && (K & 3) == 0; }
+  __device__ const float* chunk(const Ctx&, int x, int k) const { return (x < X && k < K) ? p + (int64_t)x * ld + k : nullptr; }
 };
 
 struct DenseX {  // row/column index contiguous in memory
@@ -105,6 +112,8 @@ struct DenseX {  // row/column index contiguous in memory
     if (x + 3 < X) r.w = q[3];
     return r;
   }
+  __host__ __device__ bool dma_ok() const { return vec && (X & 3) == 0; }
+  __device__ const float* chunk(const Ctx&, int x, int k) const { return (x < X && k < K) ? p + (int64_t)k * ld + x : nullptr; }
 };
 
 // Geometry of one implicit-GEMM launch.  Rows enumerate a grid [N][GH][GW] of "anchor" positions;
@@ -179,6 +188,15 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     }
     return make_float4(elem(c, k), elem(c, k + 1), elem(c, k + 2), elem(c, k + 3));
   }
+  __host__ __device__ bool dma_ok() const { return g.vec != 0; }
+  __device__ const float* chunk(const Ctx& c, int, int k) const {
+    if (c.rn < 0) return nullptr;
+    const int t = (int)fdiv((uint32_t)k, g.dC);
+    if (t >= g.ntaps()) return nullptr;
+    bool ok;
+    const float* q = pixel(c, t, ok);
+    return ok ? q + (k - t * g.C) : nullptr;
+  }
 };
 
 struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [tap][Cred][Nout]
@@ -209,6 +227,12 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
     if (x + 2 < Nout) r.z = q[2];
     if (x + 3 < Nout) r.w = q[3];
     return r;
+  }
+  __host__ __device__ bool dma_ok() const { return vec && (Nout & 3) == 0; }
+  __device__ const float* chunk(const Ctx&, int x, int k) const {
+    bool ok;
+    const float* q = rowp(k, ok);
+    return (ok && x < Nout) ? q + x : nullptr;
   }
 };
 
@@ -267,6 +291,8 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     }
     return make_float4(v[0], v[1], v[2], v[3]);
   }
+  __host__ __device__ bool dma_ok() const { return g.vec != 0; }
+  __device__ const float* chunk(const Ctx& cx, int x, int k) const;  // defined after the constant chunks below
 };
 
 // =====================================================================================
@@ -342,6 +368,49 @@ struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 at
 };
 
 #ifndef FMI_HOST_EMU
+// epilogue shared by the kernels: register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31 of its 32x32 tile
+template <class EP, class T>
+__device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T::TN], int M, int N, int row0, int col0, int lh, int l31) {
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= M) continue;
+      const int64_t off = ep.row_off(row);
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        const int col = col0 + j * 32 + l31;
+        if (col < N) ep.store(off, col, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// constant 16-byte chunks the LDS-DMA path reads for out-of-range / synthetic operand elements
+static __device__ __attribute__((aligned(16))) float fmi_chunk_zero[4] = {0.f, 0.f, 0.f, 0.f};
+static __device__ __attribute__((aligned(16))) float fmi_chunk_one[4] = {1.f, 0.f, 0.f, 0.f};
+
+__device__ inline const float* WgradAX::chunk(const Ctx& cx, int x, int k) const {
+  if (k >= g.Mdim()) return nullptr;
+  if (x == ones_row) return fmi_chunk_one;
+  if (cx.t0 >= g.ntaps()) return nullptr;
+  const uint32_t n = fdiv((uint32_t)k, g.dG);
+  const uint32_t rem = (uint32_t)k - n * (uint32_t)(g.GH * g.GW);
+  const uint32_t gy = fdiv(rem, g.dGW);
+  const uint32_t gx = rem - gy * (uint32_t)g.GW;
+  const int i = (int)fdiv((uint32_t)cx.t0, g.dntx), j = cx.t0 - i * g.ntx;
+  int iy = (int)gy * g.S + g.dy0 + g.ystep * i, ix = (int)gx * g.S + g.dx0 + g.xstep * j;
+  if (g.pad_mode) {
+    iy = reflect_idx(iy, g.IH);
+    ix = reflect_idx(ix, g.IW);
+  }
+  if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return nullptr;
+  return p + ((int64_t)((int)n * g.IH + iy) * g.IW + ix) * g.cstride + cx.c0;
+}
+#endif
+
+#ifndef FMI_HOST_EMU
 // =====================================================================================
 // The kernel.  grid.x = tiles_m*tiles_n (XCD-remapped), grid.y = batch*ksplit.
 // =====================================================================================
@@ -410,14 +479,17 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NLA], rb[NLB];
-  auto gload = [&](int k0) {
+  float4 ra0[NLA], rb0[NLB];
+#if FMI_EXP & 16
+  float4 ra1[NLA], rb1[NLB];
+#endif
+  auto gload = [&](float4 (&ra)[NLA], float4 (&rb)[NLB], int k0) {
 #pragma unroll
     for (int j = 0; j < NLA; ++j) ra[j] = aact[j] ? la.load4(ca[j], m0 + ax[j], k0 + ak[j]) : zero4();
 #pragma unroll
     for (int j = 0; j < NLB; ++j) rb[j] = bact[j] ? lb.load4(cb[j], n0 + bx[j], k0 + bk[j]) : zero4();
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const float4 (&ra)[NLA], const float4 (&rb)[NLB], int buf) {
     float* a = As + buf * BK * LDA;
     float* b = Bs + buf * BK * LDB;
 #pragma unroll
@@ -445,20 +517,11 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
       }
     }
   };
-
-  if (k_begin < k_end) {
-    gload(k_begin);
-    lstore(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    const bool more = k0 + BK < k_end;
-    if (more) gload(k0 + BK);
+  // one 16-deep tile from LDS buffer `buf`: all fragments first (counted lgkmcnt waits let the MFMAs start as they
+  // arrive), then 8 x TM x TN back-to-back MFMAs: the LDS latency is exposed once per tile, not once per k-pair
+  auto compute = [&](int buf) {
     const float* a = As + buf * BK * LDA + wm + l31;
     const float* b = Bs + buf * BK * LDB + wn + l31;
-    // all fragments of the 16-deep tile first (counted lgkmcnt waits let the MFMAs start as they arrive),
-    // then 8 x TM x TN back-to-back MFMAs: the LDS latency is exposed once per tile, not once per k-pair
     float fa[BK / 2][T::TM], fb[BK / 2][T::TN];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -474,26 +537,217 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
+  };
+
+  if (k_begin < k_end) {
+    gload(ra0, rb0, k_begin);
+    lstore(ra0, rb0, 0);
+  }
+#if FMI_EXP & 16
+  // two register sets: the loads of tile t+2 are issued before tile t is computed (prefetch distance 2)
+  if (k_begin + BK < k_end) gload(ra1, rb1, k_begin + BK);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+    if (k0 + 2 * BK < k_end) gload(ra0, rb0, k0 + 2 * BK);
+    compute(buf);
+    if (k0 + BK < k_end) lstore(ra1, rb1, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    if (k0 + BK >= k_end) break;
+    if (k0 + 3 * BK < k_end) gload(ra1, rb1, k0 + 3 * BK);
+    compute(buf);
+    if (k0 + 2 * BK < k_end) lstore(ra0, rb0, buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
+#else
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = k0 + BK < k_end;
+#if !(FMI_EXP & 2)
+    if (more) gload(ra0, rb0, (FMI_EXP & 8) ? k_begin : k0 + BK);
+#endif
+    compute(buf);
+#if !(FMI_EXP & 4)
+    if (more) lstore(ra0, rb0, buf ^ 1);
+#endif
+#if !(FMI_EXP & 1)
+    __syncthreads();
+#endif
+    buf ^= 1;
+  }
+#endif
 
-  // epilogue: register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31 of its 32x32 tile
+  store_tile<EP, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);
+}
+
+// =====================================================================================
+// LDS-DMA pipeline (the default whenever both operands can be fetched in aligned 16-byte chunks).
+//
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), three 16-deep
+// stages in flight: the copies of tile t+2 are issued right after the barrier that opens tile t, so a copy has two MFMA
+// phases (~2 x 2048 cycles per wave) to land -- the register-staged kernel above exposes about half of the global-load
+// latency and pays ~15 % in staging instructions (profiles/: ablation table in DESIGN.md).
+//
+// LDS image of a stage (a DMA instruction writes 64 consecutive 16-byte chunks, lane-linear):
+//   reduction-contiguous operand (KMODE): [row][16 k] ; chunk position (row, q ^ ((row >> 2) & 3)) holds k-quarter q: the
+//       XOR goes on the SOURCE address of the copy and on the reader's address; ds_read_b128 fragment reads are
+//       conflict-free in the hardware's 16-lane groups.
+//   row-contiguous operand: [16 k][rows]; ds_read_b32 fragment reads of 32 consecutive rows per half-wave.
+// MFMA k assignment inside a tile: half-wave h (= lane >> 5) owns k = 8h .. 8h+7, step s multiplies A[:, 8h+s] B[8h+s, :]
+// (any pairing is legal as long as both operands use the same one).
+// Synchronisation: one raw s_barrier per tile.  Before it every wave waits (counted vmcnt) for its own copies of tile t;
+// after it the stage read two tiles ago is free (all waves finished its ds_reads before arriving) and is refilled.
+// =====================================================================================
+template <class L, int BX, int NL>
+struct DmaCoords {
+  int x[NL], k[NL];
+  typename L::Ctx c[NL];
+};
+
+template <class LA, class LB, class EP, class T>
+__global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
+                                                           int ksplit, int kchunk) {
+  constexpr int BM = T::BM, BN = T::BN, BK = 16, NST = 3;
+  constexpr int NLA = BM / 64, NLB = BN / 64;  // 16-byte copies per thread per tile
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "DMA tiles are multiples of 64");
+  constexpr int STAGE = (BM + BN) * BK;  // floats
+  __shared__ __attribute__((aligned(1024))) float lds[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int zb = blockIdx.y / ksplit, zs = blockIdx.y - zb * ksplit;
+  la.set_batch(zb);
+  lb.set_batch(zb);
+  ep.set_batch(zb);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = zs * kchunk;
+  int k_end = k_begin + kchunk;
+  if (k_end > K) k_end = K;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+
+  // which chunk of the tile each of this thread's copies fetches (position p = j*256 + tid of the lane-linear image)
+  int ax[NLA], ak[NLA], bx[NLB], bk[NLB];
+  typename LA::Ctx ca[NLA];
+  typename LB::Ctx cb[NLB];
 #pragma unroll
-  for (int i = 0; i < T::TM; ++i) {
+  for (int j = 0; j < NLA; ++j) {
+    const int p = j * 256 + tid;
+    if (LA::KMODE) {
+      ax[j] = p >> 2;
+      ak[j] = ((p & 3) ^ ((ax[j] >> 2) & 3)) * 4;
+    } else {
+      ak[j] = p / (BM / 4);
+      ax[j] = (p % (BM / 4)) * 4;
+    }
+    ca[j] = la.prep(m0 + ax[j]);
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row >= M) continue;
-      const int64_t off = ep.row_off(row);
+  for (int j = 0; j < NLB; ++j) {
+    const int p = j * 256 + tid;
+    if (LB::KMODE) {
+      bx[j] = p >> 2;
+      bk[j] = ((p & 3) ^ ((bx[j] >> 2) & 3)) * 4;
+    } else {
+      bk[j] = p / (BN / 4);
+      bx[j] = (p % (BN / 4)) * 4;
+    }
+    cb[j] = lb.prep(n0 + bx[j]);
+  }
+
+  f32x16 acc[T::TM][T::TN];
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) {
-        const int col = n0 + wn + j * 32 + l31;
-        if (col < N) ep.store(off, col, acc[i][j][r]);
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // The copies are issued from inline asm: hipcc then neither counts them nor drains them (it would put an
+  // s_waitcnt vmcnt(0) in front of every ds_read that follows a compiler-visible LDS-DMA); their completion is counted
+  // by hand below.  M0 carries the wave-uniform LDS byte address; lane l writes bytes [16 l, 16 l + 16) after it.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  auto glds16 = [&](const float* g, uint32_t dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+  };
+  auto issue = [&](int k0, int st) {
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + wid * 256) * 4u);  // this wave's 1 KiB slice
+    const uint32_t sb = sa + BM * BK * 4;
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      const float* g = la.chunk(ca[j], m0 + ax[j], k0 + ak[j]);
+      if (!g) g = fmi_chunk_zero;
+      glds16(g, sa + j * 4096);
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      const float* g = lb.chunk(cb[j], n0 + bx[j], k0 + bk[j]);
+      if (!g) g = fmi_chunk_zero;
+      glds16(g, sb + j * 4096);
+    }
+  };
+  auto compute = [&](int st) {
+    const float* sa = lds + st * STAGE;
+    const float* sb = sa + BM * BK;
+    float fa[T::TM][8], fb[T::TN][8];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      if (LA::KMODE) {
+        const int r = wm + i * 32 + l31, sw = (r >> 2) & 3;
+        const float4 v0 = *reinterpret_cast<const float4*>(sa + r * 16 + ((2 * lh) ^ sw) * 4);
+        const float4 v1 = *reinterpret_cast<const float4*>(sa + r * 16 + ((2 * lh + 1) ^ sw) * 4);
+        fa[i][0] = v0.x, fa[i][1] = v0.y, fa[i][2] = v0.z, fa[i][3] = v0.w;
+        fa[i][4] = v1.x, fa[i][5] = v1.y, fa[i][6] = v1.z, fa[i][7] = v1.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fa[i][s] = sa[(8 * lh + s) * BM + wm + i * 32 + l31];
       }
     }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+      if (LB::KMODE) {
+        const int r = wn + j * 32 + l31, sw = (r >> 2) & 3;
+        const float4 v0 = *reinterpret_cast<const float4*>(sb + r * 16 + ((2 * lh) ^ sw) * 4);
+        const float4 v1 = *reinterpret_cast<const float4*>(sb + r * 16 + ((2 * lh + 1) ^ sw) * 4);
+        fb[j][0] = v0.x, fb[j][1] = v0.y, fb[j][2] = v0.z, fb[j][3] = v0.w;
+        fb[j][4] = v1.x, fb[j][5] = v1.y, fb[j][6] = v1.z, fb[j][7] = v1.w;
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) fb[j][s] = sb[(8 * lh + s) * BN + wn + j * 32 + l31];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+  };
+
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  if (nt > 0) issue(k_begin, 0);
+  if (nt > 1) issue(k_begin + BK, 1);
+  int st = 0, st2 = 2;  // stage of tile t, stage of tile t+2
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");  // tile t landed, tile t+1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) issue(k_begin + (t + 2) * BK, st2);
+    compute(st);
+    st = st == NST - 1 ? 0 : st + 1;
+    st2 = st2 == NST - 1 ? 0 : st2 + 1;
   }
+
+  store_tile<EP, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);
 }
 
 // Host-side launcher: picks the tile from N (and M), validates the 32-bit index ranges the kernel assumes.
@@ -510,10 +764,18 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
   }
   const int64_t gy = (int64_t)batch * ksplit;
   if (gy > 65535) return FMI_ERR_UNSUPPORTED;
+  const bool dma = !(FMI_EXP & 32) && la.dma_ok() && lb.dma_ok();
 #define FMI_LAUNCH(TILE)                                                                                      \
   do {                                                                                                        \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                 \
     if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                   \
+    if constexpr (TILE::BM % 64 == 0 && TILE::BN % 64 == 0) {                                                 \
+      if (dma) {                                                                                              \
+        hipLaunchKernelGGL((gemm_dma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
+                           0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                              \
+        break;                                                                                                \
+      }                                                                                                       \
+    }                                                                                                         \
     hipLaunchKernelGGL((gemm_mfma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
                        0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                                  \
   } while (0)
