@@ -142,5 +142,5 @@ _LIB = None
 def lib() -> Library:
     global _LIB
     if _LIB is None:
-        _LIB = Library()
+        _LIB = Library(os.environ.get("FMI_LIB_PATH", LIB_PATH))  # FMI_LIB_PATH: an experimental build of the same library
     return _LIB

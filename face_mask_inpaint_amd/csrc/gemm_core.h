@@ -13,6 +13,10 @@
 //  * workgroup ids are remapped so that each XCD (private L2) walks a contiguous range of tiles.
 #pragma once
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+extern "C" long fmi_debug_launch_counter;
+#include <type_traits>
 
 #ifndef FMI_HOST_EMU
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -89,8 +93,20 @@ struct DenseK {  // reduction index contiguous in memory
     return r;
   }
   // LDS-DMA path: address of the 16-byte chunk (x, k..k+3), nullptr = zeros
+  // LDS-DMA path.  dprep(x, kq): per-thread constants of one copy slot (row x, k offset kq inside the tile);
+  // tile(k0): wave-uniform state of a 16-deep tile; chunk(): address of the 16-byte chunk, nullptr = zeros.
   __host__ __device__ bool dma_ok() const { return vec && (K & 3) == 0; }
-  __device__ const float* chunk(const Ctx&, int x, int k) const { return (x < X && k < K) ? p + (int64_t)x * ld + k : nullptr; }
+  struct DCtx {
+    int64_t off;
+    int kq;
+  };
+  struct Tile {
+    const float* base;
+    int krem;
+  };
+  __device__ DCtx dprep(int x, int kq) const { return DCtx{(int64_t)x * ld + kq, x < X ? kq : 0x40000000}; }
+  __device__ Tile tile(int k0) const { return Tile{p + k0, K - k0}; }
+  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kq < t.krem ? t.base + d.off : nullptr; }
 };
 
 struct DenseX {  // row/column index contiguous in memory
@@ -113,7 +129,17 @@ struct DenseX {  // row/column index contiguous in memory
     return r;
   }
   __host__ __device__ bool dma_ok() const { return vec && (X & 3) == 0; }
-  __device__ const float* chunk(const Ctx&, int x, int k) const { return (x < X && k < K) ? p + (int64_t)k * ld + x : nullptr; }
+  struct DCtx {
+    int64_t off;
+    int kr;
+  };
+  struct Tile {
+    const float* base;
+    int krem;
+  };
+  __device__ DCtx dprep(int x, int kr) const { return DCtx{(int64_t)kr * ld + x, x < X ? kr : 0x40000000}; }
+  __device__ Tile tile(int k0) const { return Tile{p + (int64_t)k0 * ld, K - k0}; }
+  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kr < t.krem ? t.base + d.off : nullptr; }
 };
 
 // Geometry of one implicit-GEMM launch.  Rows enumerate a grid [N][GH][GW] of "anchor" positions;
@@ -188,14 +214,37 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     }
     return make_float4(elem(c, k), elem(c, k + 1), elem(c, k + 2), elem(c, k + 3));
   }
-  __host__ __device__ bool dma_ok() const { return g.vec != 0; }
-  __device__ const float* chunk(const Ctx& c, int, int k) const {
-    if (c.rn < 0) return nullptr;
-    const int t = (int)fdiv((uint32_t)k, g.dC);
-    if (t >= g.ntaps()) return nullptr;
-    bool ok;
-    const float* q = pixel(c, t, ok);
-    return ok ? q + (k - t * g.C) : nullptr;
+  // LDS-DMA path: only when a 16-deep tile always lies inside one tap (C % 16 == 0) and padding is zeros; the tap is then
+  // wave-uniform (scalar decode per tile) and a copy's address is one 64-bit add of a per-thread and a per-tile offset.
+  __host__ __device__ bool dma_ok() const { return g.vec != 0 && (g.C & 15) == 0 && !g.pad_mode; }
+  struct DCtx {
+    int64_t boff;  // element offset of (anchor pixel, channel kq); the tap adds a wave-uniform offset
+    int ry, rx;    // anchor coordinates; rows beyond M get ry far outside the image
+  };
+  struct Tile {
+    int dy, dx;    // tap displacement; past the last tap: dy far outside the image (zeros)
+    int64_t uoff;
+  };
+  __device__ DCtx dprep(int x, int kq) const {
+    const Ctx c = prep(x);
+    DCtx d;
+    d.ry = c.rn < 0 ? -0x20000000 : c.ry;
+    d.rx = c.rx;
+    d.boff = ((int64_t)((c.rn < 0 ? 0 : c.rn) * g.IH + c.ry) * g.IW + c.rx) * g.cstride + kq;
+    return d;
+  }
+  __device__ Tile tile(int k0) const {
+    const int tp = (int)fdiv((uint32_t)k0, g.dC);
+    const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
+    Tile t;
+    t.dy = tp < g.ntaps() ? g.ystep * i : -0x20000000;
+    t.dx = g.xstep * j;
+    t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * g.cstride + (k0 - tp * g.C);
+    return t;
+  }
+  __device__ const float* chunk(const DCtx& d, const Tile& t) const {
+    const bool ok = (unsigned)(d.ry + t.dy) < (unsigned)g.IH && (unsigned)(d.rx + t.dx) < (unsigned)g.IW;
+    return ok ? p + d.boff + t.uoff : nullptr;
   }
 };
 
@@ -228,12 +277,20 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
     if (x + 3 < Nout) r.w = q[3];
     return r;
   }
-  __host__ __device__ bool dma_ok() const { return vec && (Nout & 3) == 0; }
-  __device__ const float* chunk(const Ctx&, int x, int k) const {
+  __host__ __device__ bool dma_ok() const { return vec && (Nout & 3) == 0 && (g.C & 15) == 0; }
+  struct DCtx {
+    int off;  // kr*Nout + x, or -1 for columns beyond Nout
+  };
+  struct Tile {
+    const float* base;  // row of (tap, first channel of the tile); nullptr past the last tap
+  };
+  __device__ DCtx dprep(int x, int kr) const { return DCtx{x < Nout ? kr * Nout + x : -1}; }
+  __device__ Tile tile(int k0) const {
     bool ok;
-    const float* q = rowp(k, ok);
-    return (ok && x < Nout) ? q + x : nullptr;
+    const float* q = rowp(k0, ok);
+    return Tile{ok ? q : nullptr};
   }
+  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? t.base + d.off : nullptr; }
 };
 
 struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), reduction = anchors
@@ -292,7 +349,25 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     return make_float4(v[0], v[1], v[2], v[3]);
   }
   __host__ __device__ bool dma_ok() const { return g.vec != 0; }
-  __device__ const float* chunk(const Ctx& cx, int x, int k) const;  // defined after the constant chunks below
+  struct DCtx {
+    Ctx c;
+    int x, kr, dy, dx;
+  };
+  struct Tile {
+    int k0;
+  };
+  __device__ DCtx dprep(int x, int kr) const {
+    DCtx d;
+    d.c = prep(x);
+    d.x = x;
+    d.kr = kr;
+    const int i = (int)fdiv((uint32_t)d.c.t0, g.dntx), j = d.c.t0 - i * g.ntx;
+    d.dy = g.dy0 + g.ystep * i;
+    d.dx = g.dx0 + g.xstep * j;
+    return d;
+  }
+  __device__ Tile tile(int k0) const { return Tile{k0}; }
+  __device__ const float* chunk(const DCtx& d, const Tile& t) const;  // defined after the constant chunks below
 };
 
 // =====================================================================================
@@ -391,22 +466,22 @@ __device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T:
 static __device__ __attribute__((aligned(16))) float fmi_chunk_zero[4] = {0.f, 0.f, 0.f, 0.f};
 static __device__ __attribute__((aligned(16))) float fmi_chunk_one[4] = {1.f, 0.f, 0.f, 0.f};
 
-__device__ inline const float* WgradAX::chunk(const Ctx& cx, int x, int k) const {
+__device__ inline const float* WgradAX::chunk(const DCtx& d, const Tile& t) const {
+  const int k = t.k0 + d.kr;
   if (k >= g.Mdim()) return nullptr;
-  if (x == ones_row) return fmi_chunk_one;
-  if (cx.t0 >= g.ntaps()) return nullptr;
+  if (d.x == ones_row) return fmi_chunk_one;
+  if (d.c.t0 >= g.ntaps()) return nullptr;
   const uint32_t n = fdiv((uint32_t)k, g.dG);
   const uint32_t rem = (uint32_t)k - n * (uint32_t)(g.GH * g.GW);
   const uint32_t gy = fdiv(rem, g.dGW);
   const uint32_t gx = rem - gy * (uint32_t)g.GW;
-  const int i = (int)fdiv((uint32_t)cx.t0, g.dntx), j = cx.t0 - i * g.ntx;
-  int iy = (int)gy * g.S + g.dy0 + g.ystep * i, ix = (int)gx * g.S + g.dx0 + g.xstep * j;
+  int iy = (int)gy * g.S + d.dy, ix = (int)gx * g.S + d.dx;
   if (g.pad_mode) {
     iy = reflect_idx(iy, g.IH);
     ix = reflect_idx(ix, g.IW);
   }
   if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return nullptr;
-  return p + ((int64_t)((int)n * g.IH + iy) * g.IW + ix) * g.cstride + cx.c0;
+  return p + ((int64_t)((int)n * g.IH + iy) * g.IW + ix) * g.cstride + d.c.c0;
 }
 #endif
 
@@ -611,8 +686,8 @@ template <class LA, class LB, class EP, class T>
 __global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
                                                            int ksplit, int kchunk) {
   constexpr int BM = T::BM, BN = T::BN, BK = 16, NST = 3;
-  constexpr int NLA = BM / 64, NLB = BN / 64;  // 16-byte copies per thread per tile
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "DMA tiles are multiples of 64");
+  // copies: a tile image has BX*4 16-byte chunks = BX/16 wave instructions; wave w issues instructions w, w+4, ...
+  constexpr int NLA = (BM + 63) / 64, NLB = (BN + 63) / 64;
   constexpr int STAGE = (BM + BN) * BK;  // floats
   __shared__ __attribute__((aligned(1024))) float lds[NST * STAGE];
 
@@ -631,33 +706,37 @@ __global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, 
   const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
 
   // which chunk of the tile each of this thread's copies fetches (position p = j*256 + tid of the lane-linear image)
-  int ax[NLA], ak[NLA], bx[NLB], bk[NLB];
-  typename LA::Ctx ca[NLA];
-  typename LB::Ctx cb[NLB];
+  typename LA::DCtx da[NLA];
+  typename LB::DCtx db[NLB];
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
     const int p = j * 256 + tid;
+    int x, k;
     if (LA::KMODE) {
-      ax[j] = p >> 2;
-      ak[j] = ((p & 3) ^ ((ax[j] >> 2) & 3)) * 4;
+      x = p >> 2;
+      k = ((p & 3) ^ ((x >> 2) & 3)) * 4;
     } else {
-      ak[j] = p / (BM / 4);
-      ax[j] = (p % (BM / 4)) * 4;
+      k = p / (BM / 4);
+      x = (p % (BM / 4)) * 4;
     }
-    ca[j] = la.prep(m0 + ax[j]);
+    da[j] = la.dprep(m0 + x, k);
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
     const int p = j * 256 + tid;
+    int x, k;
     if (LB::KMODE) {
-      bx[j] = p >> 2;
-      bk[j] = ((p & 3) ^ ((bx[j] >> 2) & 3)) * 4;
+      x = p >> 2;
+      k = ((p & 3) ^ ((x >> 2) & 3)) * 4;
     } else {
-      bk[j] = p / (BN / 4);
-      bx[j] = (p % (BN / 4)) * 4;
+      k = p / (BN / 4);
+      x = (p % (BN / 4)) * 4;
     }
-    cb[j] = lb.prep(n0 + bx[j]);
+    db[j] = lb.dprep(n0 + x, k);
   }
+  // wave-uniform: does copy slot j of this wave exist (tiles narrower than 64 rows fill only waves 0..1)
+  const int na_w = (BM % 64 == 0) ? NLA : (wid * 64 < BM * 4 ? 1 : 0);
+  const int nb_w = (BN % 64 == 0) ? NLB : (wid * 64 < BN * 4 ? 1 : 0);
 
   f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -681,15 +760,19 @@ __global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, 
   auto issue = [&](int k0, int st) {
     const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + wid * 256) * 4u);  // this wave's 1 KiB slice
     const uint32_t sb = sa + BM * BK * 4;
+    const typename LA::Tile ta = la.tile(k0);
+    const typename LB::Tile tb = lb.tile(k0);
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
-      const float* g = la.chunk(ca[j], m0 + ax[j], k0 + ak[j]);
+      if (BM % 64 != 0 && !na_w) break;
+      const float* g = la.chunk(da[j], ta);
       if (!g) g = fmi_chunk_zero;
       glds16(g, sa + j * 4096);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
-      const float* g = lb.chunk(cb[j], n0 + bx[j], k0 + bk[j]);
+      if (BN % 64 != 0 && !nb_w) break;
+      const float* g = lb.chunk(db[j], tb);
       if (!g) g = fmi_chunk_zero;
       glds16(g, sb + j * 4096);
     }
@@ -737,8 +820,19 @@ __global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, 
   if (nt > 1) issue(k_begin + BK, 1);
   int st = 0, st2 = 2;  // stage of tile t, stage of tile t+2
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");  // tile t landed, tile t+1 may be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < nt) {  // tile t landed, tile t+1 may stay in flight: counted wait on this wave's own copies
+      if (BM % 64 == 0 && BN % 64 == 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+      } else {
+        const int nw = na_w + nb_w;
+        if (nw == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + 2 < nt) issue(k_begin + (t + 2) * BK, st2);
@@ -764,12 +858,22 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
   }
   const int64_t gy = (int64_t)batch * ksplit;
   if (gy > 65535) return FMI_ERR_UNSUPPORTED;
-  const bool dma = !(FMI_EXP & 32) && la.dma_ok() && lb.dma_ok();
+  // FMI_DMA_OFF (debug): bit 0 dense GEMM, bit 1 conv forward / adjoint, bit 2 weight gradient -> use the register-staged kernel
+  static const int dma_off = getenv("FMI_DMA_OFF") ? atoi(getenv("FMI_DMA_OFF")) : 0;
+  const int family = std::is_same<LA, ConvK>::value ? 2 : (std::is_same<LA, WgradAX>::value ? 4 : 1);
+  bool dma = !(FMI_EXP & 32) && !(dma_off & family) && la.dma_ok() && lb.dma_ok();
+  if (const char* r = getenv("FMI_DMA_OFF_RANGE")) {  // debug: "a:b" = launches a <= i < b of this process use the register-staged kernel
+    long a = 0, b = 0;
+    sscanf(r, "%ld:%ld", &a, &b);
+    const long i = fmi_debug_launch_counter++;
+    if (i >= a && i < b) dma = false;
+    if (getenv("FMI_DMA_TRACE")) fprintf(stderr, "[fmi launch %ld] family %d M %d N %d K %d batch %d ksplit %d dma %d (eligible %d %d)\n", i, family, M, N, K, batch, ksplit, (int)dma, (int)la.dma_ok(), (int)lb.dma_ok());
+  }
 #define FMI_LAUNCH(TILE)                                                                                      \
   do {                                                                                                        \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                 \
     if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                   \
-    if constexpr (TILE::BM % 64 == 0 && TILE::BN % 64 == 0) {                                                 \
+    {                                                                                                         \
       if (dma) {                                                                                              \
         hipLaunchKernelGGL((gemm_dma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
                            0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                              \

@@ -26,6 +26,7 @@ for (n, h, ci, co, k) in SHAPES:
     d, oh, ow = FF.conv_desc(n, h, h, ci, co, k, k, 1, k // 2)
     y = torch.empty(n, oh, ow, co, device=dev)
     convs.append((d, x, w, y, 2.0 * n * oh * ow * ci * co * k * k))
+a2 = torch.randn(131072, 2304, device=dev); b2 = torch.randn(2304, 256, device=dev); c2 = torch.empty(131072, 256, device=dev)
 rounds = int(os.environ.get("ROUNDS", "2"))
 res = {}
 for r in range(rounds):
@@ -34,11 +35,13 @@ for r in range(rounds):
         out = []
         t = timeit(lambda: lib.gemm_f32(FF._p(a), FF._p(b), FF._p(c), 4096, 4096, 4096, 4096, 1, 4096, 1, 4096, 1, 1, 0, 0, 0, 1.0, 0.0, None, st))
         out.append(2 * 4096 ** 3 / t / 1e9)
+        t = timeit(lambda: lib.gemm_f32(FF._p(a2), FF._p(b2), FF._p(c2), 131072, 256, 2304, 2304, 1, 256, 1, 256, 1, 1, 0, 0, 0, 1.0, 0.0, None, st))
+        out.append(2 * 131072 * 256 * 2304 / t / 1e9)
         for d, x, w, y, fl in convs:
             t = timeit(lambda: lib.conv2d_fwd_f32(C.byref(d), FF._p(x), FF._p(w), None, None, FF._p(y), 0, 1, 0, st))
             out.append(fl / t / 1e9)
         res.setdefault(path, []).append(out)
-print("%-28s %8s " % ("variant", "gemm4k") + " ".join("%14s" % ("%dx%d^2 %d>%d" % (s[0], s[1], s[2], s[3])) for s in SHAPES))
+print("%-28s %8s %14s " % ("variant", "gemm4k", "gemm131kx256x2304") + " ".join("%14s" % ("%dx%d^2 %d>%d" % (s[0], s[1], s[2], s[3])) for s in SHAPES))
 for path, rs in res.items():
     best = [max(r[i] for r in rs) for i in range(len(rs[0]))]
     print("%-28s " % os.path.basename(path) + " ".join("%8.1f" % v if i == 0 else "%14.1f" % v for i, v in enumerate(best)))

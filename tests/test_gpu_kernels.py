@@ -85,6 +85,12 @@ CONV_CASES = [  # n, c, k, h, w, ksz, stride, pad
     (2, 8, 12, 9, 7, 3, 1, 1), (1, 3, 8, 10, 11, 3, 1, 1), (2, 16, 5, 6, 6, 1, 1, 0), (2, 8, 4, 12, 10, 3, 2, 1),
     (1, 4, 6, 9, 8, 4, 2, 1), (2, 8, 1, 7, 7, 3, 1, 0), (2, 32, 64, 33, 31, 3, 1, 1), (1, 64, 32, 40, 40, 3, 1, 1),
     (2, 128, 128, 16, 16, 3, 1, 1), (1, 32, 3, 64, 64, 3, 1, 1), (2, 256, 64, 8, 8, 1, 1, 0),
+    # LDS-DMA pipeline (C % 16 == 0, K % 4 == 0): one-tile reductions (1x1, C = 16), two-tile, narrow 128x32 / 32x128 /
+    # 64-wide tiles, stride-2 adjoints, tails in M and N, enough rows for several workgroups per CU
+    (2, 16, 16, 32, 32, 1, 1, 0), (2, 16, 16, 16, 16, 1, 1, 0), (2, 32, 16, 32, 32, 1, 1, 0), (2, 16, 64, 32, 32, 1, 1, 0),
+    (2, 16, 128, 20, 20, 1, 1, 0), (2, 16, 48, 33, 31, 3, 1, 1), (2, 32, 32, 16, 16, 3, 1, 1), (3, 64, 36, 20, 20, 3, 2, 1),
+    (2, 16, 32, 32, 32, 3, 2, 1), (2, 32, 64, 32, 32, 3, 2, 1), (2, 16, 16, 32, 32, 4, 2, 1), (2, 48, 64, 17, 19, 5, 1, 2),
+    (4, 32, 32, 128, 128, 3, 1, 1), (2, 256, 256, 24, 24, 3, 1, 1), (1, 512, 128, 14, 14, 3, 1, 1),
 ]
 
 
