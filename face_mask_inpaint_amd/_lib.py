@@ -41,6 +41,9 @@ SIGNATURES = {
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],
     "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, vp, i32, i64, vp],
+    "fmi_conv2d_thin_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, vp],
+    "fmi_conv2d_thin_dgrad_f32": [PD, vp, vp, vp, vp],
+    "fmi_conv2d_thin_wgrad_f32": [PD, vp, vp, vp, vp, vp],
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_weight_prepare_f32": [vp, i32, vp],
@@ -97,6 +100,9 @@ SIGNATURES = {
 STATUS = {0: "ok", 1: "bad argument", 2: "unsupported shape/mode", 3: "kernel launch failed"}
 
 
+PREDICATES = {"fmi_conv2d_thin_supported": [PD]}
+
+
 class FmiError(RuntimeError):
     pass
 
@@ -122,6 +128,15 @@ class Library:
             fn.argtypes = argtypes
             fn.restype = C.c_int
             setattr(self, name[4:], self._checked(name, fn))
+        for name, argtypes in PREDICATES.items():  # int-valued queries (not status codes)
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+            setattr(self, name[4:], fn)
         if strict and self.missing:
             raise FmiError(f"{path} lacks symbols {self.missing}")
 

@@ -40,6 +40,8 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   if (rc) return rc;
   if (!x || !wf || !y || batch_w < 1 || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  if (batch_w == 1 && fmi_conv2d_thin_supported(d) && aligned16(x))
+    return fmi_conv2d_thin_fwd_f32(d, x, wf, bias, residual, y, act, stream);
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
   ConvK la{x, g};
@@ -56,6 +58,8 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
   if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;  // reflect: run on the padded extent, then fmi_reflect_pad_fold_f32
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  if (batch_w == 1 && !bias && !residual && fmi_conv2d_thin_supported(d) && aligned16(dx))
+    return fmi_conv2d_thin_dgrad_f32(d, dy, wt, dx, stream);
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;
   for (int py = 0; py < s; ++py) {
@@ -93,6 +97,7 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
   if (rc) return rc;
   if (!x || !dy || !dwf || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  if (batch_w == 1 && fmi_conv2d_thin_supported(d) && aligned16(x)) return fmi_conv2d_thin_wgrad_f32(d, x, dy, dwf, dbias, stream);
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
   // the bias gradient rides along as one extra output row (needs a float4-aligned row index and shared weights)

@@ -1,0 +1,299 @@
+// 3x3 stride-1 convolution with a THIN output (K <= 4 channels): the generator's Output block
+// (base_function.py:367-398: LeakyReLU -> ReflectionPad2d(1) -> conv3x3(32 -> 3) -> tanh) at 1024x1024.
+// As a GEMM it has N = 3 columns: the matrix-core kernel runs it at 5 TFLOP/s while the tensor traffic
+// (1.07 GB of fp32 activations per batch of 8) needs ~0.2 ms of HBM time.  These kernels are bandwidth kernels:
+//
+//   lane layout: G = C/4 lanes per pixel, lane j of a group owns channels 4j..4j+3 (one 16-byte load per tap, a group
+//   reads a pixel's C floats as one contiguous run); 64/G pixels per wave.  The 9 x 4 x K weights of a lane's
+//   channel chunk live in registers for the whole kernel.
+//   forward : 9 loads + 36 K FMAs per lane and pixel, xor-shuffle reduction over the G lanes, bias/residual/tanh.
+//   dgrad   : dx[q][c] = sum_t sum_k w[t][c][k] dy[.][k]; with reflect padding the fold of the padded gradient is fused:
+//             a pixel next to the border also collects the taps that the reflection mapped onto it.
+//   wgrad   : per-lane accumulators [9][4][K] over a strided range of pixels, reduced over the wave's pixel groups by
+//             shuffles, over the workgroup's waves through LDS, over workgroups by fp32 atomics; dbias rides along.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect1(int i, int n) {  // nn.ReflectionPad2d index map
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+struct ThinArgs {
+  const float* x;    // [N,H,W,C] pixel pitch xcs
+  const float* w;    // wf[9][C][K]
+  const float* bias;
+  const float* res;  // y layout
+  float* y;          // [N,H,W,K] pixel pitch ycs
+  int N, H, W, C, K, xcs, ycs, pad_mode, act;
+};
+
+template <int K>
+__device__ __forceinline__ void load_w(float (&wr)[9][4][K], const float* __restrict__ w, int C, int c0, bool is_wt = false) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        wr[t][e][k] = is_wt ? w[((int64_t)t * K + k) * C + c0 + e]   // wt[tap][K][C]
+                            : w[((int64_t)t * C + c0 + e) * K + k];  // wf[tap][C][K]
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a, int G, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & (G - 1), grp = lane / G, ppw = 64 / G;
+  const int c0 = 4 * j;
+  float wr[9][4][K];
+  load_w<K>(wr, a.w, a.C, c0);
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t base = wave * ppw; base < total; base += nwaves * ppw) {
+    const int64_t p = base + grp;
+    const bool live = p < total;
+    const int64_t pp = live ? p : total - 1;
+    const int n = (int)(pp / ((int64_t)a.H * a.W));
+    const int rem = (int)(pp - (int64_t)n * a.H * a.W);
+    const int oy = rem / a.W, ox = rem - oy * a.W;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        int iy = oy + ty - 1, ix = ox + tx - 1;
+        bool ok = true;
+        if (a.pad_mode) {
+          iy = reflect1(iy, a.H);
+          ix = reflect1(ix, a.W);
+        } else {
+          ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          iy = ok ? iy : 0;
+          ix = ok ? ix : 0;
+        }
+        float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[k] = fmaf(xv[e], wr[ty * 3 + tx][e][k], acc[k]);
+      }
+    }
+    for (int m = 1; m < G; m <<= 1)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+    if (live && j == 0) {
+      const int64_t o = pp * a.ycs;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float v = acc[k];
+        if (a.bias) v += a.bias[k];
+        if (a.res) v += a.res[o + k];
+        if (a.act == 1) v = tanhf(v);
+        else if (a.act == 2) v = fmaxf(v, 0.f);
+        a.y[o + k] = v;
+      }
+    }
+  }
+}
+
+// dx[q][c0..c0+3]; dy = a.y (read), dx = written through `dx`
+template <int K>
+__global__ void __launch_bounds__(256) thin_dgrad_kernel(ThinArgs a, float* __restrict__ dx, int64_t total) {
+  // one lane per (pixel, 4-channel chunk): consecutive lanes = consecutive chunks of a pixel -> coalesced float4 stores
+  const int CG = a.C >> 2;
+  float wr[9][4][K];
+  int cur_c0 = -1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % CG);
+    const int64_t q = i / CG;
+    const int c0 = 4 * j;
+    if (c0 != cur_c0) {  // constant per thread whenever the stride (gridDim*256) is a multiple of CG: loaded once
+      load_w<K>(wr, a.w, a.C, c0, true);
+      cur_c0 = c0;
+    }
+    const int n = (int)(q / ((int64_t)a.H * a.W));
+    const int rem = (int)(q - (int64_t)n * a.H * a.W);
+    const int qy = rem / a.W, qx = rem - qy * a.W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // padded coordinates u that map onto q: u = q + 1 always; with reflect padding also u = 0 (q == 1), u = H + 1 (q == H - 2)
+    int uy[3], ux[3], nuy = 0, nux = 0;
+    uy[nuy++] = qy + 1;
+    ux[nux++] = qx + 1;
+    if (a.pad_mode) {
+      if (qy == 1) uy[nuy++] = 0;
+      if (qy == a.H - 2) uy[nuy++] = a.H + 1;
+      if (qx == 1) ux[nux++] = 0;
+      if (qx == a.W - 2) ux[nux++] = a.W + 1;
+    }
+    for (int iy = 0; iy < nuy; ++iy) {
+      for (int ix = 0; ix < nux; ++ix) {
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const int py = uy[iy] - ty, px = ux[ix] - tx;  // output pixel whose tap (ty, tx) reads padded position u
+            if ((unsigned)py >= (unsigned)a.H || (unsigned)px >= (unsigned)a.W) continue;
+            const float* g = a.y + ((int64_t)(n * a.H + py) * a.W + px) * a.ycs;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+              const float gv = g[k];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[e] = fmaf(gv, wr[ty * 3 + tx][e][k], acc[e]);
+            }
+          }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dx + q * a.xcs + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a, float* __restrict__ dwf, float* __restrict__ dbias, int G,
+                                                         int64_t total) {
+  __shared__ float red[4][9 * 4 * K + K][16];  // [wave][value][channel chunk j]  (G <= 16)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int j = lane & (G - 1), grp = lane / G, ppw = 64 / G;
+  const int c0 = 4 * j;
+  float acc[9][4][K], bacc[K];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[t][e][k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) bacc[k] = 0.f;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t base = wave * ppw; base < total; base += nwaves * ppw) {
+    const int64_t p = base + grp;
+    if (p >= total) continue;
+    const int n = (int)(p / ((int64_t)a.H * a.W));
+    const int rem = (int)(p - (int64_t)n * a.H * a.W);
+    const int oy = rem / a.W, ox = rem - oy * a.W;
+    float gv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      gv[k] = a.y[p * a.ycs + k];
+      bacc[k] += gv[k];
+    }
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        int iy = oy + ty - 1, ix = ox + tx - 1;
+        if (a.pad_mode) {
+          iy = reflect1(iy, a.H);
+          ix = reflect1(ix, a.W);
+        } else if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) {
+          continue;
+        }
+        const float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[ty * 3 + tx][e][k] = fmaf(xv[e], gv[k], acc[ty * 3 + tx][e][k]);
+      }
+    }
+  }
+  // over the wave's pixel groups (lanes that share j), then over the workgroup's waves, then over workgroups
+  for (int m = G; m < 64; m <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[t][e][k] += __shfl_xor(acc[t][e][k], m, 64);
+#pragma unroll
+    for (int k = 0; k < K; ++k) bacc[k] += __shfl_xor(bacc[k], m, 64);
+  }
+  if (grp == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[wid][(t * 4 + e) * K + k][j] = acc[t][e][k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wid][36 * K + k][j] = bacc[k];
+  }
+  __syncthreads();
+  const int nval = 36 * K;
+  for (int i = threadIdx.x; i < nval * G; i += 256) {
+    const int v = i / G, jj = i - v * G;
+    const float s = red[0][v][jj] + red[1][v][jj] + red[2][v][jj] + red[3][v][jj];
+    const int t = v / (4 * K), e = (v / K) & 3, k = v % K;
+    atomicAdd(dwf + ((int64_t)t * a.C + 4 * jj + e) * K + k, s);
+  }
+  if (dbias && threadIdx.x < K) {  // every chunk lane j saw the same pixels: take j = 0
+    const int k = threadIdx.x;
+    atomicAdd(dbias + k, red[0][36 * K + k][0] + red[1][36 * K + k][0] + red[2][36 * K + k][0] + red[3][36 * K + k][0]);
+  }
+}
+
+bool thin_shape_ok(const fmi_conv_desc* d) {
+  const int cg = d->C / 4;
+  return d->K >= 1 && d->K <= 4 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->C % 4 == 0 && cg >= 1 &&
+         cg <= 16 && (cg & (cg - 1)) == 0 && d->x_cstride % 4 == 0 && d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W;
+}
+
+}  // namespace
+
+#define THIN_DISPATCH(KERNEL, ...)                                                              \
+  switch (d->K) {                                                                               \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;  \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;  \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break;  \
+    default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); break; \
+  }
+
+// 1 if the thin-output kernels take this geometry (same-size 3x3 stride-1 pad-1 convolution, K <= 4, C = 4..64 power of two)
+extern "C" int fmi_conv2d_thin_supported(const fmi_conv_desc* d) { return d && thin_shape_ok(d) ? 1 : 0; }
+
+extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                                       const float* residual, float* y, int act, void* stream) {
+  if (!d || !x || !wf || !y || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
+  if (!thin_shape_ok(d) || ((uintptr_t)x & 15)) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  ThinArgs a{x, wf, bias, residual, y, d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, act};
+  const int G = d->C / 4;
+  const int64_t total = (int64_t)d->N * d->H * d->W;
+  const int64_t waves = (total + 64 / G - 1) / (64 / G);
+  const int grid = (int)(waves / 4 > 8192 ? 8192 : (waves + 3) / 4);
+  THIN_DISPATCH(thin_fwd_kernel, a, G, total);
+  return fmi_launch_status();
+}
+
+/* dx (layout of x) = adjoint of the thin convolution applied to dy; pad_mode = reflect includes the fold of the padded
+ * gradient (what fmi_conv2d_dgrad_f32 on the padded extent + fmi_reflect_pad_fold_f32 compute in two passes). */
+extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream) {
+  if (!d || !dy || !wt || !dx) return FMI_ERR_BAD_ARG;
+  if (!thin_shape_ok(d) || ((uintptr_t)dx & 15)) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  ThinArgs a{nullptr, wt, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
+  const int64_t total = (int64_t)d->N * d->H * d->W * (d->C / 4);
+  int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  THIN_DISPATCH(thin_dgrad_kernel, a, dx, total);
+  return fmi_launch_status();
+}
+
+/* dwf[9][C][K] += x^T dy, dbias[k] += sum dy (dbias may be NULL); caller zeroes both. */
+extern "C" int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
+                                         void* stream) {
+  if (!d || !x || !dy || !dwf) return FMI_ERR_BAD_ARG;
+  if (!thin_shape_ok(d) || ((uintptr_t)x & 15)) return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  ThinArgs a{x, nullptr, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
+  const int G = d->C / 4;
+  const int64_t total = (int64_t)d->N * d->H * d->W;
+  const int64_t waves = (total + 64 / G - 1) / (64 / G);
+  const int grid = (int)(waves / 4 > 1024 ? 1024 : (waves + 3) / 4);
+  THIN_DISPATCH(thin_wgrad_kernel, a, dwf, dbias, G, total);
+  return fmi_launch_status();
+}

@@ -230,7 +230,12 @@ class _Conv2d(torch.autograd.Function):
         k = wf.shape[2]
         gx = gwf = gb = gres = None
         if ctx.needs_input_grad[0]:
-            if pad_mode == 1:  # adjoint w.r.t. the reflection-padded tensor, then fold (base_function.py:390)
+            d0, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+            if pad_mode == 1 and lib.conv2d_thin_supported(C.byref(d0)):  # thin output: adjoint and fold in one pass
+                gx = torch.empty_like(x)
+                with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
+                    lib.conv2d_thin_dgrad_f32(C.byref(d0), _p(gy), _p(ctx.wt), _p(gx), _st())
+            elif pad_mode == 1:  # adjoint w.r.t. the reflection-padded tensor, then fold (base_function.py:390)
                 hp, wp = h + 2 * pad, w + 2 * pad
                 d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0)
                 gpad = torch.empty((n, hp, wp, c), device=x.device, dtype=torch.float32)

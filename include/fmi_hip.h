@@ -91,6 +91,16 @@ int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* w
  * GEMM as one extra row of ones -- no separate pass over dy; caller zeroes it. */
 int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
                          int batch_w, int64_t w_bstride, void* stream);
+/* Thin-output 3x3 convolution (K <= 4 output channels, stride 1, pad 1, C = 4..64 a power of two): the Output block of
+ * the PICNet generator, base_function.py:367-398 (LeakyReLU -> ReflectionPad2d(1) -> conv3x3(32 -> 3) -> tanh) at 1024^2.
+ * Bandwidth kernels; fmi_conv2d_fwd_f32 / _wgrad_f32 / _dgrad_f32 (zero padding) route to them by themselves.
+ * fmi_conv2d_thin_dgrad_f32 also takes pad_mode = reflect on the UNPADDED extent and includes the fold of the padded gradient
+ * (one pass instead of fmi_conv2d_dgrad_f32 on the padded extent + fmi_reflect_pad_fold_f32). */
+int fmi_conv2d_thin_supported(const fmi_conv_desc* d);
+int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                            const float* residual, float* y, int act, void* stream);
+int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);
+int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias, void* stream);
 /* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
 int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);
 /* fold the gradient w.r.t. a reflection-padded tensor [N,H+2p,W+2p,C] back onto [N,H,W,C]. */

@@ -120,15 +120,16 @@ def test_conv_family(dev, FF, n, c, k, h, w, ksz, stride, pad):
     torch.testing.assert_close(dx.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
     dwf = torch.zeros_like(wf)
     lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf), None, 1, 0, st)
-    torch.testing.assert_close(dwf.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=2e-4)
+    watol = 2e-4 * max(1.0, (n * oh * ow / 2048.0) ** 0.5)  # fp32 sums over all pixels, on both sides: error grows like sqrt(#terms)
+    torch.testing.assert_close(dwf.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=watol)
     db = torch.zeros(k, device=dev)
     lib.bias_grad_f32(FF._p(gyh), n * oh * ow, k, k, FF._p(db), st)
-    torch.testing.assert_close(db.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=watol)
     if (ksz * ksz * c) % 4 == 0:  # fused: the bias gradient is an extra row of the weight-gradient GEMM
         dwf2, db2 = torch.zeros_like(wf), torch.zeros(k, device=dev)
         lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gyh), FF._p(dwf2), FF._p(db2), 1, 0, st)
-        torch.testing.assert_close(dwf2.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=2e-4)
-        torch.testing.assert_close(db2.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(dwf2.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=watol)
+        torch.testing.assert_close(db2.cpu(), gy.sum((0, 2, 3)), rtol=1e-4, atol=watol)
 
 
 def test_conv_transpose_and_autograd(dev, FF):
@@ -476,3 +477,46 @@ def test_ssim_metric(dev, golden):
     torch.testing.assert_close(ssim(a, b).cpu(), fx["mean"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(ssim(a, b, size_average=False).cpu(), fx["per_image"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(SSIM()(a, a).cpu(), fx["same"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# thin-output 3x3 convolution (K <= 4): the generator's Output block, base_function.py:367-398
+@pytest.mark.parametrize("n,c,k,h,w,pad_mode,act", [(2, 32, 3, 20, 24, 1, 1), (1, 32, 3, 64, 64, 1, 1), (2, 8, 1, 9, 7, 0, 0), (2, 4, 4, 5, 6, 1, 0),
+                                                    (1, 64, 2, 12, 12, 0, 2), (3, 16, 3, 3, 3, 1, 0), (1, 32, 3, 130, 70, 0, 0)])
+def test_thin_output_conv(dev, FF, n, c, k, h, w, pad_mode, act):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(h * 10 + c + k)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt_ = (torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(k, generator=g, requires_grad=True)
+    xp = F.pad(x, (1, 1, 1, 1), mode="reflect") if pad_mode else F.pad(x, (1, 1, 1, 1))
+    pre = F.conv2d(xp, wt_, b)
+    y = torch.tanh(pre) if act == 1 else (torch.relu(pre) if act == 2 else pre)
+    gpre = torch.randn(pre.shape, generator=g)  # cotangent of the pre-activation (the activation backward is a separate kernel)
+    pre.backward(gpre)
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, 3, 3, 1, 1, pad_mode)
+    assert lib.conv2d_thin_supported(C.byref(d)) == 1
+    wf, wtp = [t.to(dev) for t in pack(wt_.detach())]
+    xh, gh, bd = nhwc(x.detach()).to(dev), nhwc(gpre).to(dev), b.detach().to(dev)
+    st = FF._st()
+    out = torch.full((n, h, w, k), float("nan"), device=dev)
+    lib.conv2d_fwd_f32(C.byref(d), FF._p(xh), FF._p(wf), FF._p(bd), None, FF._p(out), act, 1, 0, st)  # routes to the thin kernel
+    torch.testing.assert_close(out.cpu(), nhwc(y.detach()), rtol=1e-5, atol=1e-5)
+    res = torch.randn(n, h, w, k, generator=g).to(dev)
+    out2 = torch.empty_like(out)
+    lib.conv2d_thin_fwd_f32(C.byref(d), FF._p(xh), FF._p(wf), None, FF._p(res), FF._p(out2), 0, st)
+    torch.testing.assert_close(out2.cpu(), nhwc((pre - b.view(1, -1, 1, 1)).detach()) + res.cpu(), rtol=1e-5, atol=1e-5)
+    dx = torch.full((n, h, w, c), float("nan"), device=dev)
+    lib.conv2d_thin_dgrad_f32(C.byref(d), FF._p(gh), FF._p(wtp), FF._p(dx), st)
+    torch.testing.assert_close(dx.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
+    dwf, db = torch.zeros_like(wf), torch.zeros(k, device=dev)
+    lib.conv2d_wgrad_f32(C.byref(d), FF._p(xh), FF._p(gh), FF._p(dwf), FF._p(db), 1, 0, st)  # routes to the thin kernel
+    tol = 1e-4 * max(1.0, (n * h * w / 2048.0) ** 0.5)
+    torch.testing.assert_close(dwf.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=tol)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=tol)
+    if pad_mode == 0:  # the generic entry point routes zero-padded thin adjoints too
+        dx2 = torch.full((n, h, w, c), float("nan"), device=dev)
+        lib.conv2d_dgrad_f32(C.byref(d), FF._p(gh), FF._p(wtp), None, None, FF._p(dx2), 1, 0, st)
+        torch.testing.assert_close(dx2.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
