@@ -33,6 +33,34 @@ static ConvGeom fwd_geom(const fmi_conv_desc* d, const float* x, int n_eff) {
   return g;
 }
 
+#ifndef FMI_HOST_EMU
+// y[pixel][k] = bias[k] + residual[pixel][k] (either may be null): first pass of a split-reduction convolution
+__global__ void __launch_bounds__(256) conv_split_init_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                             const float* __restrict__ res, int K, int cstride, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int64_t o = (i / K) * cstride + k;
+    float v = bias ? bias[k] : 0.f;
+    if (res) v += res[o];
+    y[o] = v;
+  }
+}
+#endif
+
+// Small feature maps with deep reductions (the 128-channel residual stacks at 32x32 and below, and the discriminator) give
+// the implicit GEMM only a handful of output tiles: split the (tap, channel) reduction over several workgroups per tile.
+static int conv_ksplit(int64_t M, int N, int K) {
+#ifdef FMI_HOST_EMU
+  return 1;
+#else
+  const int64_t tiles = ceil_div64(M, 64) * ceil_div64(N, 128);
+  if (tiles >= 256 || K < 512) return 1;
+  int64_t ks = 512 / tiles;
+  if (ks > K / 192) ks = K / 192;
+  return ks < 2 ? 1 : (int)(ks > 16 ? 16 : ks);
+#endif
+}
+
 extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
                                   const float* residual, float* y, int act, int batch_w, int64_t w_bstride,
                                   void* stream) {
@@ -40,14 +68,28 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   if (rc) return rc;
   if (!x || !wf || !y || batch_w < 1 || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+#ifndef FMI_HOST_EMU
   if (batch_w == 1 && fmi_conv2d_thin_supported(d) && aligned16(x))
     return fmi_conv2d_thin_fwd_f32(d, x, wf, bias, residual, y, act, stream);
+#endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
   ConvK la{x, g};
   ConvWX lb{wf, g, w_bstride, d->K, (d->K % 4 == 0) && aligned16(wf) && (w_bstride % 4 == 0)};
   ConvEp ep{y, bias, residual, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, act, g.dGW, g.dG,
             (int64_t)d->OH * d->OW * d->y_cstride};
+#ifndef FMI_HOST_EMU
+  const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
+  if (ks > 1) {
+    const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
+    hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
+                       d->y_cstride, total);
+    ep.bias = nullptr;
+    ep.res = nullptr;
+    ep.act = 3;
+    return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), 1, ks, (hipStream_t)stream);
+  }
+#endif
   return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), batch_w, 1, (hipStream_t)stream);
 }
 
@@ -58,8 +100,10 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
   if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;  // reflect: run on the padded extent, then fmi_reflect_pad_fold_f32
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+#ifndef FMI_HOST_EMU
   if (batch_w == 1 && !bias && !residual && fmi_conv2d_thin_supported(d) && aligned16(dx))
     return fmi_conv2d_thin_dgrad_f32(d, dy, wt, dx, stream);
+#endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;
   for (int py = 0; py < s; ++py) {
@@ -84,6 +128,20 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
       ConvWX lb{wt, g, w_bstride, d->C, (d->C % 4 == 0) && aligned16(wt) && (w_bstride % 4 == 0)};
       ConvEp ep{dx, bias, residual, GH, GW, s, py, px, d->H, d->W, d->x_cstride, 0, g.dGW, g.dG,
                 (int64_t)d->H * d->W * d->x_cstride};
+#ifndef FMI_HOST_EMU
+      const int ks = (s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1;
+      if (ks > 1) {
+        const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
+        hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
+                           d->C, d->x_cstride, total);
+        ep.bias = nullptr;
+        ep.res = nullptr;
+        ep.act = 3;
+        rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, ks, (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
+#endif
       rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), batch_w, 1, (hipStream_t)stream);
       if (rc) return rc;
     }
@@ -97,7 +155,9 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
   if (rc) return rc;
   if (!x || !dy || !dwf || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+#ifndef FMI_HOST_EMU
   if (batch_w == 1 && fmi_conv2d_thin_supported(d) && aligned16(x)) return fmi_conv2d_thin_wgrad_f32(d, x, dy, dwf, dbias, stream);
+#endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
   // the bias gradient rides along as one extra output row (needs a float4-aligned row index and shared weights)

@@ -413,6 +413,10 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
     return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
   }
   __device__ void store(int64_t off, int col, float v) const {
+    if (act == 3) {  // split reduction: y was initialised with bias + residual, the partial sums meet through fp32 atomics
+      atomicAdd(y + off + col, v);
+      return;
+    }
     if (bias) v += bias[col];
     if (res) v += res[off + col];
     if (act == 1) v = tanhf(v);
