@@ -43,30 +43,28 @@ __device__ __forceinline__ void load_w(float (&wr)[9][4][K], const float* __rest
 }
 
 template <int K>
-__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a, int G, int total) {
-  constexpr int PIX = 1;  // pixels per lane group and iteration: 18 independent 16-byte loads in flight per lane
+__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a, int G, int64_t total) {
   const int lane = threadIdx.x & 63;
-  const int j = lane & (G - 1), grp = lane / G, ppw = (64 / G) * PIX;
+  const int j = lane & (G - 1), grp = lane / G, ppw = 64 / G;
   const int c0 = 4 * j;
   float wr[9][4][K];
   load_w<K>(wr, a.w, a.C, c0);
-  const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(((int64_t)gridDim.x * 256) >> 6);
-  const int HW = a.H * a.W;
-  for (int base = wave * ppw; base < total; base += nwaves * ppw) {
-    float acc[PIX][K];
-    int pp[PIX];
-    bool live[PIX];
-    float4 v[PIX][9];
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t base = wave * ppw; base < total; base += nwaves * ppw) {
+    const int64_t p = base + grp;
+    const bool live = p < total;
+    const int64_t pp = live ? p : total - 1;
+    const int n = (int)(pp / ((int64_t)a.H * a.W));
+    const int rem = (int)(pp - (int64_t)n * a.H * a.W);
+    const int oy = rem / a.W, ox = rem - oy * a.W;
+    float acc[K];
 #pragma unroll
-    for (int u = 0; u < PIX; ++u) {
-      const int p = base + grp * PIX + u;
-      live[u] = p < total;
-      pp[u] = live[u] ? p : total - 1;
-      const int n = pp[u] / HW, rem = pp[u] - n * HW;
-      const int oy = rem / a.W, ox = rem - oy * a.W;
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        int iy = oy + ty - 1, ix = ox + tx - 1;
         bool ok = true;
         if (a.pad_mode) {
           iy = reflect1(iy, a.H);
@@ -76,41 +74,28 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a, int G, int to
           iy = ok ? iy : 0;
           ix = ok ? ix : 0;
         }
-        v[u][t] = *reinterpret_cast<const float4*>(a.x + ((int64_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0);
-        if (!ok) v[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < PIX; ++u) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) acc[u][k] = 0.f;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float xv[4] = {v[u][t].x, v[u][t].y, v[u][t].z, v[u][t].w};
+        float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int k = 0; k < K; ++k) acc[u][k] = fmaf(xv[e], wr[t][e][k], acc[u][k]);
+          for (int k = 0; k < K; ++k) acc[k] = fmaf(xv[e], wr[ty * 3 + tx][e][k], acc[k]);
       }
     }
     for (int m = 1; m < G; m <<= 1)
 #pragma unroll
-      for (int u = 0; u < PIX; ++u)
+      for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+    if (live && j == 0) {
+      const int64_t o = pp * a.ycs;
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[u][k] += __shfl_xor(acc[u][k], m, 64);
-#pragma unroll
-    for (int u = 0; u < PIX; ++u) {
-      if (live[u] && j == u % G) {  // spread the stores of a group's pixels over its lanes
-        const int64_t o = (int64_t)pp[u] * a.ycs;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          float r = acc[u][k];
-          if (a.bias) r += a.bias[k];
-          if (a.res) r += a.res[o + k];
-          if (a.act == 1) r = tanhf(r);
-          else if (a.act == 2) r = fmaxf(r, 0.f);
-          a.y[o + k] = r;
-        }
+      for (int k = 0; k < K; ++k) {
+        float v = acc[k];
+        if (a.bias) v += a.bias[k];
+        if (a.res) v += a.res[o + k];
+        if (a.act == 1) v = tanhf(v);
+        else if (a.act == 2) v = fmaxf(v, 0.f);
+        a.y[o + k] = v;
       }
     }
   }
@@ -280,9 +265,9 @@ extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, c
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
   if (total >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
-  const int64_t waves = (total + 1 * (64 / G) - 1) / (1 * (64 / G));
-  const int grid = (int)(waves / 4 > 16384 ? 16384 : (waves + 3) / 4);
-  THIN_DISPATCH(thin_fwd_kernel, a, G, (int)total);
+  const int64_t waves = (total + 64 / G - 1) / (64 / G);
+  const int grid = (int)(waves / 4 > 8192 ? 8192 : (waves + 3) / 4);
+  THIN_DISPATCH(thin_fwd_kernel, a, G, total);
   return fmi_launch_status();
 }
 

@@ -45,6 +45,44 @@ class _prof:
         return False
 
 
+class _ZeroSlab:
+    """Bump allocator of pre-zeroed device memory for the many small accumulators the kernels need (atomically accumulated weight /
+    bias gradients, norm statistics, loss scalars): one 32 MB fill replaces hundreds of 5-microsecond fill launches per
+    training step.  A slice is handed out once and never recycled, so it is zero when its kernel starts; the slab's storage lives as
+    long as any slice does."""
+
+    SLAB_BYTES = 32 << 20
+    MAX_BYTES = 4 << 20
+    buf = None
+    off = 0
+
+    @classmethod
+    def take(cls, shape, device, dtype=torch.float32):
+        if isinstance(shape, int):
+            shape = (shape,)
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        nbytes = numel * torch.empty((), dtype=dtype).element_size()
+        if nbytes > cls.MAX_BYTES or nbytes == 0 or device.type != "cuda":
+            return torch.zeros(shape, device=device, dtype=dtype)
+        nbytes_al = (nbytes + 255) & ~255
+        if cls.buf is None or cls.buf.device != device or cls.off + nbytes_al > cls.SLAB_BYTES:
+            cls.buf = torch.zeros(cls.SLAB_BYTES, device=device, dtype=torch.uint8)
+            cls.off = 0
+        out = cls.buf[cls.off:cls.off + nbytes].view(dtype).view(shape)
+        cls.off += nbytes_al
+        return out
+
+
+def _zeros(shape, device, dtype=torch.float32):
+    return _ZeroSlab.take(tuple(shape) if not isinstance(shape, int) else shape, device, dtype)
+
+
+def _zeros_like(t):
+    return _ZeroSlab.take(tuple(t.shape), t.device, t.dtype)
+
+
 def _L():
     return _lib.lib()
 
@@ -176,7 +214,7 @@ class _WeightPrepare(torch.autograd.Function):
                 e.dw = dw.data_ptr()
                 e.rows, e.C, e.taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
                 grads[i] = dw
-            scratch = torch.zeros(len(live), device=ctx.sig.device, dtype=torch.float32)
+            scratch = _zeros(len(live), ctx.sig.device, torch.float32)
             lib.weight_grad_f32(entries, len(live), _p(scratch), _st())
         return (None,) + tuple(grads)
 
@@ -250,15 +288,15 @@ class _Conv2d(torch.autograd.Function):
                     lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
-            gwf = torch.zeros_like(wf)
+            gwf = _zeros_like(wf)
             want_gb = ctx.has[0] and ctx.needs_input_grad[2]
             fuse = want_gb and (kh * kw * c) % 4 == 0
             if fuse:
-                gb = torch.zeros(k, device=x.device, dtype=torch.float32)
+                gb = _zeros(k, x.device, torch.float32)
             with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), _p(gb) if fuse else None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2] and gb is None:
-            gb = torch.zeros(k, device=x.device, dtype=torch.float32)
+            gb = _zeros(k, x.device, torch.float32)
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
@@ -267,6 +305,22 @@ class _Conv2d(torch.autograd.Function):
 
 def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE):
     return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act)
+
+
+_BIAS_GRAD_MEMO = [None, None, -1]  # (cotangent tensor, its column sums)
+
+
+def _bias_grad_of(gy, cb):
+    """sum of gy over all pixels.  The main and the bypass ConvTranspose2d of a ResBlockDecoder (base_function.py:308-364) are
+    summed, so both receive the SAME cotangent tensor: the second request is answered from the first (one pass over up to
+    1 GB instead of two).  The memo keeps that tensor alive, so its address cannot be recycled while it is the key."""
+    m = _BIAS_GRAD_MEMO
+    if m[0] is not None and m[0].data_ptr() == gy.data_ptr() and m[0].shape == gy.shape and m[0]._version == gy._version and m[2] == gy._version:
+        return m[1].clone()
+    gb = _zeros(cb, gy.device, torch.float32)
+    _L().bias_grad_f32(_p(gy), gy.numel() // cb, cb, cb, _p(gb), _st())
+    m[:] = [gy, gb, gy._version]
+    return gb.clone()
 
 
 class _ConvTranspose2d(torch.autograd.Function):
@@ -307,12 +361,11 @@ class _ConvTranspose2d(torch.autograd.Function):
             with _prof(f"convT_dgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
-            gwf = torch.zeros_like(wf)
+            gwf = _zeros_like(wf)
             with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
-            gb = torch.zeros(cb, device=x.device, dtype=torch.float32)
-            lib.bias_grad_f32(_p(gy), gy.numel() // cb, cb, cb, _p(gb), _st())
+            gb = _bias_grad_of(gy, cb)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
         return gx, gwf, gb, gres, None, None, None, None, None, None
@@ -441,7 +494,7 @@ class _Resize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         n, h, w, c = ctx.shape
-        gx = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
+        gx = _zeros(ctx.shape, g.device, torch.float32)
         _L().resize_bilinear_bwd_f32(_p(g.contiguous()), _p(gx), n, h, w, c, g.shape[1], g.shape[2], _p(ctx.std), _st())
         return gx, None, None, None, None
 
@@ -457,7 +510,7 @@ class _InstNormAct(torch.autograd.Function):
         _chk(x, gamma, beta)
         lib = _L()
         n, h, w, c = x.shape
-        sums = torch.zeros((n, c, 2), device=x.device, dtype=torch.float64)
+        sums = _zeros((n, c, 2), x.device, torch.float64)
         stats = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
         lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), n, h * w, c, eps, _st())
         y = torch.empty_like(x)
@@ -472,11 +525,11 @@ class _InstNormAct(torch.autograd.Function):
         x, stats, gamma, beta = ctx.saved_tensors
         n, h, w, c = x.shape
         g = g.contiguous()
-        red = torch.zeros((n, c, 2), device=x.device, dtype=torch.float64)
+        red = _zeros((n, c, 2), x.device, torch.float64)
         lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), n, h * w, c, ctx.slope, _st())
         gx = torch.empty_like(x)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(beta)
+        dg = _zeros_like(gamma)
+        db = _zeros_like(beta)
         lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
                                    n, h * w, c, ctx.slope, _st())
         return gx, dg, db, None, None
@@ -569,7 +622,7 @@ class _ScaleAddParam(torch.autograd.Function):
         g = g.contiguous()
         go = torch.empty_like(g)
         _L().axpy_dev_f32(_p(g), _p(gamma), None, _p(go), g.numel(), _st())
-        gg = torch.zeros_like(gamma)
+        gg = _zeros_like(gamma)
         _L().dot_f32(_p(g), _p(o), g.numel(), 1.0, _p(gg), _st())
         return go, gg, g
 
@@ -675,7 +728,7 @@ class _SelfAttention(torch.autograd.Function):
         csum = sum(v.shape[2] for v in vs)
         if lse is not None and FUSED_ATTENTION and (d, csum // 32) in ((64, 8), (32, 8), (32, 4), (64, 4)) and all(g is not None for g in gos):
             gos = [g.contiguous() for g in gos]
-            gq = torch.zeros_like(q)
+            gq = _zeros_like(q)
             gvs = [torch.empty_like(v) for v in vs]
             delta = torch.empty((n, t), device=q.device, dtype=torch.float32)
             c1 = vs[0].shape[2]
@@ -690,8 +743,8 @@ class _SelfAttention(torch.autograd.Function):
         P = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         dP = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
         gos = [g.contiguous() if g is not None else None for g in gos]
-        gq = torch.zeros_like(q)
-        gvs = [torch.zeros_like(v) if g is not None else None for v, g in zip(vs, gos)]
+        gq = _zeros_like(q)
+        gvs = [_zeros_like(v) if g is not None else None for v, g in zip(vs, gos)]
         if all(g is None for g in gos):
             return (gq,) + tuple(gvs)
         for n0 in range(0, n, ngm):
@@ -732,7 +785,7 @@ class _ReduceLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kind, a, b, c0, scale):
         _chk(a, b)
-        out = torch.zeros((), device=a.device, dtype=torch.float32)
+        out = _zeros((), a.device, torch.float32)
         _L().reduce_loss_f32(kind, _p(a), _p(b), a.numel(), c0, scale, _p(out), _st())
         ctx.save_for_backward(a, b)
         ctx.cfg = (kind, c0, scale)
@@ -802,7 +855,7 @@ class _ContextualLoss(torch.autograd.Function):
         lib = _L()
         n, p, c = x.shape
         dev = x.device
-        mu = torch.zeros(c, device=dev, dtype=torch.float32)
+        mu = _zeros(c, dev, torch.float32)
         lib.cx_channel_mean_f32(_p(y), _p(mu), n * p, c, _st())
         xn, yn = torch.empty_like(x), torch.empty_like(y)
         xi, yi = torch.empty(n * p, device=dev), torch.empty(n * p, device=dev)
@@ -819,7 +872,7 @@ class _ContextualLoss(torch.autograd.Function):
         carg = torch.empty(n * p, device=dev, dtype=torch.int32)
         lib.cx_cols_f32(_p(cxij), _p(cmax), C.c_void_p(carg.data_ptr()), n, p, _st())
         cx = torch.empty(n, device=dev)
-        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        loss = _zeros((), dev, torch.float32)
         lib.cx_loss_f32(_p(cmax), _p(cx), _p(loss), n, p, scale, _st())
         ctx.save_for_backward(xn, yn, xi, cosm, cxij, dmin, amin, rsum, carg, cx)
         ctx.cfg = (h, scale)
@@ -876,7 +929,7 @@ class _Linear(torch.autograd.Function):
             gw = torch.empty_like(w)
             gemm_raw(_p(g), _p(x), _p(gw), o, k, n, (1, o), (k, 1), (k, 1), alpha=ctx.alpha, tag="linear_bwd")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(o, device=g.device, dtype=torch.float32)
+            gb = _zeros(o, g.device, torch.float32)
             _L().bias_grad_f32(_p(g), n, o, o, _p(gb), _st())
         return gx, gw, gb, None
 
@@ -909,7 +962,7 @@ class _ScaleChannels(torch.autograd.Function):
             gx = torch.empty_like(x)
             _L().scale_channels_f32(_p(g), _p(s), _p(gx), n, p, c, _st())
         if ctx.needs_input_grad[1]:
-            gs = torch.zeros_like(s)
+            gs = _zeros_like(s)
             _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), n, p, c, _st())
         return gx, gs
 
@@ -1008,11 +1061,11 @@ class _NoiseBiasAct(torch.autograd.Function):
         g = g.contiguous()
         c = y.shape[-1]
         gx = torch.empty_like(y)
-        gnw = torch.zeros(1, device=y.device, dtype=torch.float32) if (has_nw and noise is not None) else None
+        gnw = _zeros(1, y.device, torch.float32) if (has_nw and noise is not None) else None
         _L().noise_bias_act_bwd_f32(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), y.numel() // c, c, alpha, scale, _st())
         gb = None
         if has_b and ctx.needs_input_grad[1]:
-            gb = torch.zeros(c, device=y.device, dtype=torch.float32)
+            gb = _zeros(c, y.device, torch.float32)
             _L().bias_grad_f32(_p(gx), y.numel() // c, c, c, _p(gb), _st())
         return gx, gb, None, gnw, None, None
 
@@ -1090,7 +1143,7 @@ class _PReLU(torch.autograd.Function):
     def backward(ctx, g):
         x, a = ctx.saved_tensors
         c = x.shape[-1]
-        gx, ga = torch.empty_like(x), torch.zeros_like(a)
+        gx, ga = torch.empty_like(x), _zeros_like(a)
         _L().prelu_bwd_f32(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), x.numel() // c, c, _st())
         return gx, ga
 
@@ -1133,7 +1186,7 @@ class _BatchNormTrain(torch.autograd.Function):
         lib = _L()
         c = x.shape[-1]
         rows = x.numel() // c
-        sums = torch.zeros((1, c, 2), device=x.device, dtype=torch.float64)
+        sums = _zeros((1, c, 2), x.device, torch.float64)
         stats = torch.empty((1, c, 2), device=x.device, dtype=torch.float32)
         lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), 1, rows, c, eps, _st())
         y = torch.empty_like(x)
@@ -1149,9 +1202,9 @@ class _BatchNormTrain(torch.autograd.Function):
         c = x.shape[-1]
         rows = x.numel() // c
         g = g.contiguous()
-        red = torch.zeros((1, c, 2), device=x.device, dtype=torch.float64)
+        red = _zeros((1, c, 2), x.device, torch.float64)
         lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), 1, rows, c, 1.0, _st())
-        gx, dg, db = torch.empty_like(x), torch.zeros_like(gamma), torch.zeros_like(beta)
+        gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
         lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
                                    1, rows, c, 1.0, _st())
         return gx, dg, db, None
