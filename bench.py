@@ -212,6 +212,7 @@ def main():
         train_step(G, D, gopt, batch)
         torch.cuda.synchronize()
         recs, FF.PROFILE = FF.PROFILE, None
+        recs = [r for r in recs if not r[0].startswith("bytes:")]  # bandwidth-kernel records (pSp path) carry bytes, not flops
         tot_ms = sum(s.elapsed_time(e) for _, _, s, e in recs)
         tot_fl = sum(f for _, f, _, _ in recs)
         by, detail = {}, {}

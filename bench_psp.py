@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Secondary measurements for the pSp path (BASELINE.json configs[2] / configs[4]; SURVEY.md 8d targets) -- NOT the driver's
+bench (that is bench.py, the PICNet-ref training step).  One MI355X, fp32, synthetic data, random-init weights:
+
+  * train_psp step (GradualStyleEncoder IR-SE50 on src + ref, example-guided attention, StyleGAN2 256^2 decoder, masked-L2 +
+    reference-L2 + W-norm loss, fused Adam), bs 16: images/s;
+  * ModulatedConv2d: fp32 MFMA utilisation of every convolution launch inside Generator forward / backward (north_star target:
+    >= 50 % MFMA utilisation; fp32 peak 157.3 TFLOP/s -- the bf16 decoder of configs[2] is not built yet);
+  * upfirdn2d / fused noise+bias+lrelu: achieved GB/s (algorithmic bytes = in + out) against the 8 TB/s HBM roofline, for the
+    256^2 decoder and for the 1024^2 decoder of configs[4] (4 images per GPU).
+
+Prints ONE JSON line.  LPIPS / ArcFace-ID terms of the reference's training script need downloaded weights and are off."""
+import argparse
+import json
+import time
+import types
+
+import torch
+
+FP32_MFMA_PEAK = 157.3
+HBM_PEAK_GBS = 8000.0
+
+
+def synth(n, dev, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, 3, 256, 256, generator=g) - 0.5) / 0.5
+    ref = (torch.rand(n, 3, 256, 256, generator=g) - 0.5) / 0.5
+    y = (torch.rand(n, 3, 256, 256, generator=g) - 0.5) / 0.5
+    m = torch.zeros(n, 256, 256)
+    yy, xx = torch.meshgrid(torch.arange(256), torch.arange(256), indexing="ij")
+    for i in range(n):
+        cy, cx = 176 + int(torch.randint(-16, 17, (1,), generator=g)), 128 + int(torch.randint(-16, 17, (1,), generator=g))
+        ry, rx = 56 + int(torch.randint(-12, 13, (1,), generator=g)), 80 + int(torch.randint(-12, 13, (1,), generator=g))
+        m[i] = ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).float()
+    return x.to(dev), ref.to(dev), y.to(dev), m.to(dev)
+
+
+def summarise(recs):
+    conv = [(t, f, s.elapsed_time(e)) for t, f, s, e in recs if not t.startswith("bytes:")]
+    byt = [(t, f, s.elapsed_time(e)) for t, f, s, e in recs if t.startswith("bytes:")]
+    out = {}
+    if conv:
+        fl, ms = sum(f for _, f, _ in conv), sum(m for _, _, m in conv)
+        out["mfma"] = {"launches": len(conv), "algorithmic_tflop": round(fl / 1e12, 3), "kernel_ms": round(ms, 3),
+                       "tflops": round(fl / ms / 1e9, 2), "utilisation_fp32": round(fl / ms / 1e9 / FP32_MFMA_PEAK, 4)}
+    for key in ("upfirdn2d", "noise_bias_act"):
+        sel = [(f, m) for t, f, m in byt if t.startswith("bytes:" + key)]
+        if sel:
+            b, ms = sum(f for f, _ in sel), sum(m for _, m in sel)
+            out[key] = {"launches": len(sel), "algorithmic_GB": round(b / 1e9, 3), "kernel_ms": round(ms, 3), "GBps": round(b / ms / 1e6, 1),
+                        "frac_of_hbm_peak": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+def decoder_profile(size, n, dev, backward=True):
+    from face_mask_inpaint_amd import functional as FF
+    from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator
+
+    torch.manual_seed(0)
+    gen = Generator(size, 512, 8).to(dev)
+    lat = torch.randn(n, gen.n_latent, 512, device=dev, requires_grad=True)
+
+    def run():
+        img, _ = gen([lat], input_is_latent=True, randomize_noise=True)
+        if backward:
+            img.square().mean().backward()
+        return img
+
+    run()
+    torch.cuda.synchronize()
+    FF.PROFILE = []
+    run()
+    torch.cuda.synchronize()
+    recs, FF.PROFILE = FF.PROFILE, None
+    del gen
+    torch.cuda.empty_cache()
+    return summarise(recs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--skip-1024", action="store_true")
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "needs the MI355X (no CPU fallback)"
+    dev = torch.device("cuda:0")
+    from face_mask_inpaint_amd import functional as FF
+    from face_mask_inpaint_amd.modules.psp.criteria import pSpLoss
+    from face_mask_inpaint_amd.modules.psp.psp import pSp
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    torch.manual_seed(0)
+    opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
+                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True)
+    net = pSp(opts).to(dev).train()
+    net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
+    crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
+                                         w_norm_lambda=0.005, start_from_latent_avg=True))
+    opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
+    x, ref, y, m = synth(args.batch, dev)
+
+    def step():
+        y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True)
+        loss, _, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).item()
+    FF.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    recs, FF.PROFILE = FF.PROFILE, None
+    whole = summarise(recs)
+    del net, opt
+    torch.cuda.empty_cache()
+    out = {"metric": "train_psp images/sec (fp32, encoder trained, decoder frozen, LPIPS/ID off)", "value": round(args.batch * args.steps / dt, 2), "unit": "images/s",
+           "n_gpus": 1, "batch": args.batch, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 2), "dtype": "f32", "data": "synthetic",
+           "whole_step": whole,
+           "decoder_256_fwd_bwd": decoder_profile(256, args.batch, dev),
+           "peaks": {"fp32_mfma_tflops": FP32_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}}
+    if not args.skip_1024:
+        out["decoder_1024_fwd_bs4"] = decoder_profile(1024, 4, dev, backward=False)
+        out["decoder_1024_fwd_bwd_bs4"] = decoder_profile(1024, 4, dev, backward=True)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

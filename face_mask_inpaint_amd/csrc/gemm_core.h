@@ -665,10 +665,12 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
 // =====================================================================================
 // LDS-DMA pipeline (the default whenever both operands can be fetched in aligned 16-byte chunks).
 //
-// Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), three 16-deep
-// stages in flight: the copies of tile t+2 are issued right after the barrier that opens tile t, so a copy has two MFMA
-// phases (~2 x 2048 cycles per wave) to land -- the register-staged kernel above exposes about half of the global-load
-// latency and pays ~15 % in staging instructions (profiles/: ablation table in DESIGN.md).
+// Operand tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write) into a ring of
+// FMI_NST 16-deep stages: the copies of tile t+FMI_NST-1 are issued right after the barrier that opens tile t, so a copy
+// has a whole MFMA phase (~2048 cycles per wave, x the 3 workgroups that share a CU) to land.  The register-staged kernel
+// above exposes about half of the global-load latency and pays ~15 % in staging instructions (ablation table in
+// DESIGN.md).  Measured: 2 stages = 3 stages (125 vs 126 TFLOP/s at 4096^3) and better on narrow tiles (less LDS, more
+// workgroups per CU); 4 stages lose 5 % to occupancy.
 //
 // LDS image of a stage (a DMA instruction writes 64 consecutive 16-byte chunks, lane-linear):
 //   reduction-contiguous operand (KMODE): [row][16 k] ; chunk position (row, q ^ ((row >> 2) & 3)) holds k-quarter q: the
@@ -678,18 +680,18 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
 // MFMA k assignment inside a tile: half-wave h (= lane >> 5) owns k = 8h .. 8h+7, step s multiplies A[:, 8h+s] B[8h+s, :]
 // (any pairing is legal as long as both operands use the same one).
 // Synchronisation: one raw s_barrier per tile.  Before it every wave waits (counted vmcnt) for its own copies of tile t;
-// after it the stage read two tiles ago is free (all waves finished its ds_reads before arriving) and is refilled.
+// after it the stage read one tile ago is free (all waves finished its ds_reads before arriving) and is refilled.
 // =====================================================================================
-template <class L, int BX, int NL>
-struct DmaCoords {
-  int x[NL], k[NL];
-  typename L::Ctx c[NL];
-};
-
+#ifndef FMI_DMA_ATTR
+#define FMI_DMA_ATTR
+#endif
 template <class LA, class LB, class EP, class T>
-__global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
+__global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
                                                            int ksplit, int kchunk) {
-  constexpr int BM = T::BM, BN = T::BN, BK = 16, NST = 3;
+  #ifndef FMI_NST
+#define FMI_NST 2
+#endif
+  constexpr int BM = T::BM, BN = T::BN, BK = 16, NST = FMI_NST, DEPTH = NST - 1;  // DEPTH tiles are copied ahead of the one computed
   // copies: a tile image has BX*4 16-byte chunks = BX/16 wave instructions; wave w issues instructions w, w+4, ...
   constexpr int NLA = (BM + 63) / 64, NLB = (BN + 63) / 64;
   constexpr int STAGE = (BM + BN) * BK;  // floats
@@ -819,30 +821,46 @@ __global__ void __launch_bounds__(256) gemm_dma_f32_kernel(LA la, LB lb, EP ep, 
         for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
   };
 
-  const int nt = (k_end - k_begin + BK - 1) / BK;
-  if (nt > 0) issue(k_begin, 0);
-  if (nt > 1) issue(k_begin + BK, 1);
-  int st = 0, st2 = 2;  // stage of tile t, stage of tile t+2
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) {  // tile t landed, tile t+1 may stay in flight: counted wait on this wave's own copies
-      if (BM % 64 == 0 && BN % 64 == 0) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
-      } else {
-        const int nw = na_w + nb_w;
-        if (nw == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nw == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else if (nw == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      }
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto wait_copies = [&](int n) {  // s_waitcnt vmcnt(n): at most n of this wave's copies may still be in flight
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     }
+  };
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  const int nw = (BM % 64 == 0 && BN % 64 == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
+#pragma unroll
+  for (int p = 0; p < DEPTH; ++p)
+    if (p < nt) issue(k_begin + p * BK, p);
+  int st = 0, stn = DEPTH;  // stage of tile t, stage tile t+DEPTH goes to
+  for (int t = 0; t < nt; ++t) {
+    // tile t must have landed; the newer tiles already issued (at most DEPTH-1 of them) may stay in flight
+    int pend = nt - 1 - t;
+    if (pend > DEPTH - 1) pend = DEPTH - 1;
+    wait_copies(pend * nw);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < nt) issue(k_begin + (t + 2) * BK, st2);
+    if (t + DEPTH < nt) issue(k_begin + (t + DEPTH) * BK, stn);
+#if FMI_EXP & 64
+    __builtin_amdgcn_s_setprio(1);
+#endif
     compute(st);
+#if FMI_EXP & 64
+    __builtin_amdgcn_s_setprio(0);
+#endif
     st = st == NST - 1 ? 0 : st + 1;
-    st2 = st2 == NST - 1 ? 0 : st2 + 1;
+    stn = stn == NST - 1 ? 0 : stn + 1;
   }
 
   store_tile<EP, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);

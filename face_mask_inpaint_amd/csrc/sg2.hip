@@ -135,6 +135,56 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_kernel(const float* __rest
     out[i] = acc;
   }
 }
+// Vector form for the decoder's Blur (op/upfirdn2d.py:142-147 with up = down = 1: StyledConv up-convolutions, model.py:52-68, and
+// their gradients): C % 4 == 0, one thread per (2 adjacent output pixels, 4 channels).  The KH x (KW+1) input window of the
+// pair is read once as 16-byte loads (consecutive threads = consecutive channel chunks: coalesced), the taps are wave-uniform
+// scalars.  Algorithmic traffic = in + out bytes; the window overlap between neighbouring threads is served by L1/L2.
+template <int KH, int KW>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_fir_kernel(const float* __restrict__ in, const float* __restrict__ kernel,
+                                                                 float* __restrict__ out, int in_h, int in_w, int C4, int out_h,
+                                                                 int out_w, int pad_x0, int pad_y0, int total) {
+  float kf[KH][KW];  // flipped taps: out[oy][ox] = sum_{a,b} in[oy - pad_y0 + a][ox - pad_x0 + b] * kernel[KH-1-a][KW-1-b]
+#pragma unroll
+  for (int a = 0; a < KH; ++a)
+#pragma unroll
+    for (int b = 0; b < KW; ++b) kf[a][b] = kernel[(KH - 1 - a) * KW + (KW - 1 - b)];
+  const int pw = (out_w + 1) >> 1;  // pixel pairs per row
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int c4 = i % C4;
+    int r = i / C4;
+    const int px = r % pw;
+    r /= pw;
+    const int oy = r % out_h, n = r / out_h;
+    const int ox = 2 * px;
+    const int iy0 = oy - pad_y0, ix0 = ox - pad_x0;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    const float4* base = reinterpret_cast<const float4*>(in) + (int64_t)n * in_h * in_w * C4 + c4;
+#pragma unroll
+    for (int a = 0; a < KH; ++a) {
+      const int iy = iy0 + a;
+      if ((unsigned)iy >= (unsigned)in_h) continue;
+      const float4* row = base + (int64_t)iy * in_w * C4;
+#pragma unroll
+      for (int b = 0; b <= KW; ++b) {
+        const int ix = ix0 + b;
+        if ((unsigned)ix >= (unsigned)in_w) continue;
+        const float4 v = row[(int64_t)ix * C4];
+        if (b < KW) {
+          const float k0 = kf[a][b];
+          a0.x = fmaf(v.x, k0, a0.x), a0.y = fmaf(v.y, k0, a0.y), a0.z = fmaf(v.z, k0, a0.z), a0.w = fmaf(v.w, k0, a0.w);
+        }
+        if (b > 0) {
+          const float k1 = kf[a][b - 1];
+          a1.x = fmaf(v.x, k1, a1.x), a1.y = fmaf(v.y, k1, a1.y), a1.z = fmaf(v.z, k1, a1.z), a1.w = fmaf(v.w, k1, a1.w);
+        }
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(out) + ((int64_t)(n * out_h + oy) * out_w + ox) * C4 + c4;
+    o[0] = a0;
+    if (ox + 1 < out_w) o[C4] = a1;
+  }
+}
+
 extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int N, int in_h, int in_w, int C,
                                       int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                                       int pad_y0, int pad_y1, void* stream) {
@@ -144,6 +194,21 @@ extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, floa
   if (fh < 0 || fw < 0) return FMI_ERR_BAD_ARG;
   const int out_h = fh / down_y + 1, out_w = fw / down_x + 1;
   const int64_t total = (int64_t)N * out_h * out_w * C;
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && C % 4 == 0 && kh == kw && (kh == 4 || kh == 3 || kh == 2) &&
+      (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    const int64_t tv = (int64_t)N * out_h * ((out_w + 1) / 2) * (C / 4);
+    if (tv < (1ll << 31) && (int64_t)N * in_h * in_w * C < (1ll << 40)) {
+      const int grid = fmi_bw_grid(tv, 256);
+#define FIR_LAUNCH(K_)                                                                                                              \
+  hipLaunchKernelGGL((upfirdn2d_nhwc_fir_kernel<K_, K_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, kernel, out, in_h, in_w, \
+                     C / 4, out_h, out_w, pad_x0, pad_y0, (int)tv)
+      if (kh == 4) FIR_LAUNCH(4);
+      else if (kh == 3) FIR_LAUNCH(3);
+      else FIR_LAUNCH(2);
+#undef FIR_LAUNCH
+      return fmi_launch_status();
+    }
+  }
   hipLaunchKernelGGL(upfirdn2d_nhwc_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, in, kernel, out, in_h,
                      in_w, C, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, total);
   return fmi_launch_status();

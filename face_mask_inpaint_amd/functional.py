@@ -1049,7 +1049,8 @@ class _NoiseBiasAct(torch.autograd.Function):
         _chk(x, bias, noise, nw)
         c = x.shape[-1]
         y = torch.empty_like(x)
-        _L().noise_bias_act_f32(_p(x), _p(bias), _p(noise), _p(nw), _p(y), x.numel() // c, c, alpha, scale, _st())
+        with _prof(f"bytes:noise_bias_act|{tuple(x.shape)}", 8.0 * x.numel()):
+            _L().noise_bias_act_f32(_p(x), _p(bias), _p(noise), _p(nw), _p(y), x.numel() // c, c, alpha, scale, _st())
         ctx.save_for_backward(y, noise)
         ctx.cfg = (alpha, scale, bias is not None, nw is not None)
         return y
@@ -1086,7 +1087,9 @@ class _UpFirDnNHWC(torch.autograd.Function):
         oh = (h * up + pad[0] + pad[1] - kh) // down + 1
         ow = (w * up + pad[0] + pad[1] - kw) // down + 1
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
-        _L().upfirdn2d_nhwc_f32(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
+        # bandwidth kernel: the profile record carries algorithmic BYTES (in + out), tag prefix "bytes:"
+        with _prof(f"bytes:upfirdn2d|{n}x{h}x{w}x{c} up{up} down{down}", 4.0 * (x.numel() + y.numel())):
+            _L().upfirdn2d_nhwc_f32(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, pad, (n, h, w, c), (oh, ow))
         return y
@@ -1101,7 +1104,8 @@ class _UpFirDnNHWC(torch.autograd.Function):
         gx1 = w * up - ow * down + pad[0] - up + 1
         gy1 = h * up - oh * down + pad[0] - up + 1
         gx = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
-        _L().upfirdn2d_nhwc_f32(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
+        with _prof(f"bytes:upfirdn2d_bwd|{n}x{h}x{w}x{c} up{up} down{down}", 4.0 * (g.numel() + gx.numel())):
+            _L().upfirdn2d_nhwc_f32(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
         return gx, None, None, None, None
 
 

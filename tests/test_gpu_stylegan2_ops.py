@@ -177,3 +177,28 @@ def test_generator_against_oracle(dev):
         Wt, b = P[f"style.{i}.weight"], P[f"style.{i}.bias"]
         w = torch.nn.functional.leaky_relu(torch.nn.functional.linear(w, Wt * (1 / 8.0) * 0.01) + b * 0.01, 0.2) * 2 ** 0.5
     torch.testing.assert_close(gen.get_latent(z.to(dev)).cpu(), w, rtol=1e-4, atol=1e-5)
+
+
+def test_upfirdn2d_nhwc_vector_and_generic_paths(dev):
+    """the channels-last form used inside the decoder (Blur after up-convolutions, ToRGB skip upsampling) against the C oracle:
+    the float4 FIR path (up = down = 1, C % 4 == 0, 2/3/4-tap kernels, odd widths, crops) and the generic path; gradients too"""
+    from face_mask_inpaint_amd import functional as FF
+    from oracle import stylegan2_cpu as S  # checker
+
+    g = torch.Generator().manual_seed(11)
+    k4 = S.make_kernel([1, 3, 3, 1]) * 4
+    cases = [  # n, h, w, c, kernel, up, down, pad
+        (2, 9, 9, 8, k4, 1, 1, (1, 1)), (1, 17, 13, 64, k4, 1, 1, (1, 1)), (2, 33, 32, 16, k4, 1, 1, (2, 1)), (1, 12, 11, 4, k4, 1, 1, (1, 2)),
+        (2, 10, 7, 8, S.make_kernel([1, 2, 1]), 1, 1, (1, 1)), (1, 8, 9, 12, S.make_kernel([1, 1]), 1, 1, (1, 0)), (1, 20, 21, 8, k4, 1, 1, (-1, 2)),
+        (2, 8, 8, 3, k4, 2, 1, (2, 1)), (1, 16, 16, 8, k4, 1, 2, (1, 1)), (2, 6, 5, 4, k4, 2, 1, (2, 1)), (1, 65, 65, 32, k4, 1, 1, (1, 1)),
+    ]
+    for n, h, w, c, k, up, down, pad in cases:
+        x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+        want = S.upfirdn2d_t(x, k, up, down, pad)
+        gy = torch.randn(want.shape, generator=g)
+        (gx_want,) = torch.autograd.grad(want, x, gy)
+        xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+        got = FF.upfirdn2d_nhwc(xd, k.to(dev), up, down, pad)
+        torch.testing.assert_close(got.detach().cpu().permute(0, 3, 1, 2), want.detach(), rtol=1e-5, atol=1e-5, msg=lambda m: f"{(n, h, w, c, up, down, pad)}: {m}")
+        got.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+        torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2), gx_want, rtol=1e-5, atol=1e-5, msg=lambda m: f"grad {(n, h, w, c, up, down, pad)}: {m}")
