@@ -9,6 +9,7 @@
 //   forward : 9 loads + 36 K FMAs per lane and pixel, xor-shuffle reduction over the G lanes, bias/residual/tanh.
 //   dgrad   : dx[q][c] = sum_t sum_k w[t][c][k] dy[.][k]; with reflect padding the fold of the padded gradient is fused:
 //             a pixel next to the border also collects the taps that the reflection mapped onto it.
+//   (forward and dgrad run as the 4x4x1-MFMA row-segment forms further down; the scalar per-pixel adjoint serves the border pass)
 //   wgrad   : per-lane accumulators [9][4][K] over a strided range of pixels, reduced over the wave's pixel groups by
 //             shuffles, over the workgroup's waves through LDS, over workgroups by fp32 atomics; dbias rides along.
 #include "common.h"
@@ -42,114 +43,68 @@ __device__ __forceinline__ void load_w(float (&wr)[9][4][K], const float* __rest
                             : w[((int64_t)t * C + c0 + e) * K + k];  // wf[tap][C][K]
 }
 
+// dx[q][c0..c0+3] of one pixel; dy = a.y.  With reflect padding the fold is included: besides u = q + 1 the padded coordinates
+// u = 0 (q == 1) and u = H + 1 (q == H - 2) map onto q.
 template <int K>
-__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a, int G, int64_t total) {
-  const int lane = threadIdx.x & 63;
-  const int j = lane & (G - 1), grp = lane / G, ppw = 64 / G;
-  const int c0 = 4 * j;
-  float wr[9][4][K];
-  load_w<K>(wr, a.w, a.C, c0);
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  for (int64_t base = wave * ppw; base < total; base += nwaves * ppw) {
-    const int64_t p = base + grp;
-    const bool live = p < total;
-    const int64_t pp = live ? p : total - 1;
-    const int n = (int)(pp / ((int64_t)a.H * a.W));
-    const int rem = (int)(pp - (int64_t)n * a.H * a.W);
-    const int oy = rem / a.W, ox = rem - oy * a.W;
-    float acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.f;
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-#pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        int iy = oy + ty - 1, ix = ox + tx - 1;
-        bool ok = true;
-        if (a.pad_mode) {
-          iy = reflect1(iy, a.H);
-          ix = reflect1(ix, a.W);
-        } else {
-          ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-          iy = ok ? iy : 0;
-          ix = ok ? ix : 0;
-        }
-        float4 v = *reinterpret_cast<const float4*>(a.x + ((int64_t)(n * a.H + iy) * a.W + ix) * a.xcs + c0);
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int k = 0; k < K; ++k) acc[k] = fmaf(xv[e], wr[ty * 3 + tx][e][k], acc[k]);
-      }
-    }
-    for (int m = 1; m < G; m <<= 1)
-#pragma unroll
-      for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
-    if (live && j == 0) {
-      const int64_t o = pp * a.ycs;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        float v = acc[k];
-        if (a.bias) v += a.bias[k];
-        if (a.res) v += a.res[o + k];
-        if (a.act == 1) v = tanhf(v);
-        else if (a.act == 2) v = fmaxf(v, 0.f);
-        a.y[o + k] = v;
-      }
-    }
+__device__ __forceinline__ float4 thin_dgrad_pixel(const ThinArgs& a, const float (&wr)[9][4][K], int n, int qy, int qx) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int uy[3], ux[3], nuy = 0, nux = 0;
+  uy[nuy++] = qy + 1;
+  ux[nux++] = qx + 1;
+  if (a.pad_mode) {
+    if (qy == 1) uy[nuy++] = 0;
+    if (qy == a.H - 2) uy[nuy++] = a.H + 1;
+    if (qx == 1) ux[nux++] = 0;
+    if (qx == a.W - 2) ux[nux++] = a.W + 1;
   }
-}
-
-// dx[q][c0..c0+3]; dy = a.y (read), dx = written through `dx`
-template <int K>
-__global__ void __launch_bounds__(256) thin_dgrad_kernel(ThinArgs a, float* __restrict__ dx, int64_t total) {
-  // one lane per (pixel, 4-channel chunk): consecutive lanes = consecutive chunks of a pixel -> coalesced float4 stores
-  const int CG = a.C >> 2;
-  float wr[9][4][K];
-  int cur_c0 = -1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int j = (int)(i % CG);
-    const int64_t q = i / CG;
-    const int c0 = 4 * j;
-    if (c0 != cur_c0) {  // constant per thread whenever the stride (gridDim*256) is a multiple of CG: loaded once
-      load_w<K>(wr, a.w, a.C, c0, true);
-      cur_c0 = c0;
-    }
-    const int HW = a.H * a.W;
-    const int n = (int)q / HW, rem = (int)q - n * HW;
-    const int qy = rem / a.W, qx = rem - qy * a.W;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    // padded coordinates u that map onto q: u = q + 1 always; with reflect padding also u = 0 (q == 1), u = H + 1 (q == H - 2)
-    int uy[3], ux[3], nuy = 0, nux = 0;
-    uy[nuy++] = qy + 1;
-    ux[nux++] = qx + 1;
-    if (a.pad_mode) {
-      if (qy == 1) uy[nuy++] = 0;
-      if (qy == a.H - 2) uy[nuy++] = a.H + 1;
-      if (qx == 1) ux[nux++] = 0;
-      if (qx == a.W - 2) ux[nux++] = a.W + 1;
-    }
-    for (int iy = 0; iy < nuy; ++iy) {
-      for (int ix = 0; ix < nux; ++ix) {
+  for (int iy = 0; iy < nuy; ++iy) {
+    for (int ix = 0; ix < nux; ++ix) {
 #pragma unroll
-        for (int ty = 0; ty < 3; ++ty) {
+      for (int ty = 0; ty < 3; ++ty) {
 #pragma unroll
-          for (int tx = 0; tx < 3; ++tx) {
-            const int py = uy[iy] - ty, px = ux[ix] - tx;  // output pixel whose tap (ty, tx) reads padded position u
-            if ((unsigned)py >= (unsigned)a.H || (unsigned)px >= (unsigned)a.W) continue;
-            const float* g = a.y + ((int64_t)(n * a.H + py) * a.W + px) * a.ycs;
+        for (int tx = 0; tx < 3; ++tx) {
+          const int py = uy[iy] - ty, px = ux[ix] - tx;  // output pixel whose tap (ty, tx) reads padded position u
+          if ((unsigned)py >= (unsigned)a.H || (unsigned)px >= (unsigned)a.W) continue;
+          const float* g = a.y + ((int64_t)(n * a.H + py) * a.W + px) * a.ycs;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const float gv = g[k];
+          for (int k = 0; k < K; ++k) {
+            const float gv = g[k];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[e] = fmaf(gv, wr[ty * 3 + tx][e][k], acc[e]);
-            }
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(gv, wr[ty * 3 + tx][e][k], acc[e]);
           }
         }
       }
     }
-    *reinterpret_cast<float4*>(dx + q * a.xcs + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+  return make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// the pixels whose gradient contains folded (reflected) contributions: rows 1 and H-2, columns 1 and W-2 of every image
+template <int K>
+__global__ void __launch_bounds__(256) thin_dgrad_border_kernel(ThinArgs a, float* __restrict__ dx, int64_t total) {
+  const int CG = a.C >> 2, per_img = 2 * a.W + 2 * a.H;
+  float wr[9][4][K];
+  int cur_c0 = -1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % CG);
+    int64_t r = i / CG;
+    const int b = (int)(r % per_img), n = (int)(r / per_img);
+    if (n >= a.N) continue;
+    int qy, qx;
+    if (b < 2 * a.W) {
+      qy = b < a.W ? 1 : a.H - 2;
+      qx = b < a.W ? b : b - a.W;
+    } else {
+      const int bb = b - 2 * a.W;
+      qx = bb < a.H ? 1 : a.W - 2;
+      qy = bb < a.H ? bb : bb - a.H;
+    }
+    const int c0 = 4 * j;
+    if (c0 != cur_c0) {
+      load_w<K>(wr, a.w, a.C, c0, true);
+      cur_c0 = c0;
+    }
+    *reinterpret_cast<float4*>(dx + ((int64_t)(n * a.H + qy) * a.W + qx) * a.xcs + c0) = thin_dgrad_pixel<K>(a, wr, n, qy, qx);
   }
 }
 
@@ -237,6 +192,171 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a, float* __re
   }
 }
 
+
+// =====================================================================================
+// Matrix-core forms: v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer products per instruction; lane l = 4*blk + i
+// supplies A_blk[i] and B_blk[i], and register r of lane 4*blk + i accumulates A_blk[r] * B_blk[i] (layout probed on gfx950:
+// scripts/exp/probe_mfma4.hip) -- so the per-lane quantity (a pixel, a channel) goes on B and the 4-wide one (output channels) on A.  A block is one (pixel group, 4-channel chunk) pair: with C = 32 the 16 blocks
+// are 8 chunks x 2 pixel groups, lane = ((g * CQ + q) * 4 + i).  One instruction replaces 4 x K scalar FMAs per lane, the
+// operand loads stay the coalesced 16-byte (forward) / 4-byte (gradients) gathers of the scalar kernels above.
+// =====================================================================================
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct PixDec {
+  int n, y, x;
+};
+__device__ __forceinline__ PixDec pix_decode(int p, int HW, int W) {
+  PixDec d;
+  d.n = p / HW;
+  const int rem = p - d.n * HW;
+  d.y = rem / W;
+  d.x = rem - d.y * W;
+  return d;
+}
+
+// Work decomposition of the three kernels: a wave owns a SEGMENT of one image row (SEG pixels of row (n, y)); the three input rows
+// of the 3x3 window are wave-uniform pointers, so a pixel costs no division and no 64-bit address arithmetic.
+constexpr int SEG = 128;
+
+struct RowTask {
+  int n, y, x0;
+};
+__device__ __forceinline__ RowTask row_task(int task, int H, int segs) {  // task = ((n * H) + y) * segs + segment
+  RowTask r;
+  const int row = task / segs;
+  r.x0 = (task - row * segs) * SEG;
+  r.n = row / H;
+  r.y = row - r.n * H;
+  return r;
+}
+
+// forward: the per-lane quantity is the pixel (B operand), the 4-wide one the output channel (A operand = weights);
+// partial sums per channel chunk q are reduced over q by shuffles.
+template <int K>
+__global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(ThinArgs a, int qbits, int ntasks, int segs) {
+  const int lane = threadIdx.x & 63;
+  const int CQ = 1 << qbits, i = lane & 3, q = (lane >> 2) & (CQ - 1), g = lane >> (2 + qbits);
+  const int ppi = 4 * (16 >> qbits);  // pixels per wave and iteration
+  float wr[9][4];                     // A operand: w[t][4q+e][k = i]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)t * a.C + 4 * q + e) * K + i] : 0.f;
+  const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(((int64_t)gridDim.x * 256) >> 6);
+  for (int task = wave; task < ntasks; task += nwaves) {
+    const RowTask rt = row_task(__builtin_amdgcn_readfirstlane(task), a.H, segs);
+    const float* rp[3];
+    bool rok[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int iy = rt.y + r - 1;
+      rok[r] = true;
+      if (a.pad_mode) iy = reflect1(iy, a.H);
+      else if ((unsigned)iy >= (unsigned)a.H) rok[r] = false, iy = 0;
+      rp[r] = a.x + (int64_t)(rt.n * a.H + iy) * a.W * a.xcs + 4 * q;
+    }
+    const int xend = min(rt.x0 + SEG, a.W);
+    float* yrow = a.y + (int64_t)(rt.n * a.H + rt.y) * a.W * a.ycs;
+    const float* rrow = a.res ? a.res + (int64_t)(rt.n * a.H + rt.y) * a.W * a.ycs : nullptr;
+    for (int xb = rt.x0; xb < xend; xb += ppi) {
+      const int x = xb + g * 4 + i;
+      const bool live = x < xend;
+      int off[3];
+      bool cok[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int ix = (live ? x : xend - 1) + c - 1;
+        cok[c] = true;
+        if (a.pad_mode) ix = reflect1(ix, a.W);
+        else if ((unsigned)ix >= (unsigned)a.W) cok[c] = false, ix = 0;
+        off[c] = ix * a.xcs;
+      }
+      float4 v[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        v[t] = *reinterpret_cast<const float4*>(rp[t / 3] + off[t % 3]);
+        if (!(rok[t / 3] && cok[t % 3])) v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][0], v[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][1], v[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][2], v[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][3], v[t].w, acc, 0, 0, 0);
+      }
+      for (int m = 4; m < 4 * CQ; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+      if (live && q == 0) {
+        const int o = x * a.ycs;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          float r = acc[k];
+          if (a.bias) r += a.bias[k];
+          if (rrow) r += rrow[o + k];
+          if (a.act == 1) r = tanhf(r);
+          else if (a.act == 2) r = fmaxf(r, 0.f);
+          yrow[o + k] = r;
+        }
+      }
+    }
+  }
+}
+
+// adjoint with ZERO padding semantics: per-lane quantity = the pixel (B operand = dy of the pixels whose windows cover it), A operand =
+// w[t][4q + r][k]; lane (g, q, i) ends with dx[pixel][4q .. 4q+3] in its accumulator: one 16-byte store.  (Reflect padding: the
+// caller re-computes the two border rows / columns with thin_dgrad_border_kernel, which knows the fold.)
+template <int K>
+__global__ void __launch_bounds__(256) thin_dgrad_mfma_kernel(ThinArgs a, float* __restrict__ dx, int qbits, int ntasks, int segs) {
+  const int lane = threadIdx.x & 63;
+  const int CQ = 1 << qbits, i = lane & 3, q = (lane >> 2) & (CQ - 1), g = lane >> (2 + qbits);
+  const int ppi = 4 * (16 >> qbits);
+  float wr[9][K];  // A operand: w[t][c = 4q + i][k]   (a.w = wt[tap][K][C])
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[t][k] = a.w[((int64_t)t * K + k) * a.C + 4 * q + i];
+  const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(((int64_t)gridDim.x * 256) >> 6);
+  for (int task = wave; task < ntasks; task += nwaves) {
+    const RowTask rt = row_task(__builtin_amdgcn_readfirstlane(task), a.H, segs);
+    const float* gp[3];  // dy rows y+1, y, y-1 (tap row ty reads output row y + 1 - ty)
+    bool rok[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int py = rt.y + 1 - r;
+      rok[r] = (unsigned)py < (unsigned)a.H;
+      if (!rok[r]) py = 0;
+      gp[r] = a.y + (int64_t)(rt.n * a.H + py) * a.W * a.ycs;
+    }
+    const int xend = min(rt.x0 + SEG, a.W);
+    float* xrow = dx + (int64_t)(rt.n * a.H + rt.y) * a.W * a.xcs + 4 * q;
+    for (int xb = rt.x0; xb < xend; xb += ppi) {
+      const int x = xb + g * 4 + i;
+      const bool live = x < xend;
+      float gv[9][K];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        int px = (live ? x : xend - 1) + 1 - c;
+        const bool cok = (unsigned)px < (unsigned)a.W;
+        if (!cok) px = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float* gq = gp[r] + px * a.ycs;
+#pragma unroll
+          for (int k = 0; k < K; ++k) gv[r * 3 + c][k] = (cok && rok[r]) ? gq[k] : 0.f;
+        }
+      }
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][k], gv[t][k], acc, 0, 0, 0);
+      if (live) *reinterpret_cast<float4*>(xrow + (int64_t)x * a.xcs) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+  }
+}
+
 bool thin_shape_ok(const fmi_conv_desc* d) {
   const int cg = d->C / 4;
   return (int64_t)d->N * d->H * d->W < (1ll << 31) && d->K >= 1 && d->K <= 4 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->C % 4 == 0 && cg >= 1 &&
@@ -265,9 +385,11 @@ extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, c
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
   if (total >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
-  const int64_t waves = (total + 64 / G - 1) / (64 / G);
-  const int grid = (int)(waves / 4 > 8192 ? 8192 : (waves + 3) / 4);
-  THIN_DISPATCH(thin_fwd_kernel, a, G, total);
+  int qbits = 0;
+  while ((1 << qbits) < G) ++qbits;
+  const int segs = (d->W + SEG - 1) / SEG, ntasks = d->N * d->H * segs;
+  const int grid = ntasks / 4 > 8192 ? 8192 : (ntasks + 3) / 4;
+  THIN_DISPATCH(thin_fwd_mfma_kernel, a, qbits, ntasks, segs);
   return fmi_launch_status();
 }
 
@@ -278,9 +400,18 @@ extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy
   if (!thin_shape_ok(d) || ((uintptr_t)dx & 15)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   ThinArgs a{nullptr, wt, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
-  const int64_t total = (int64_t)d->N * d->H * d->W * (d->C / 4);
-  int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-  THIN_DISPATCH(thin_dgrad_kernel, a, dx, total);
+  int qbits = 0;
+  while ((1 << qbits) < d->C / 4) ++qbits;
+  {
+    const int segs = (d->W + SEG - 1) / SEG, ntasks = d->N * d->H * segs;
+    const int grid = ntasks / 4 > 8192 ? 8192 : (ntasks + 3) / 4;
+    THIN_DISPATCH(thin_dgrad_mfma_kernel, a, dx, qbits, ntasks, segs);
+  }
+  if (d->pad_mode) {  // the fold of the reflected border: rows / columns 1 and H-2 / W-2 are re-computed by the kernel that knows it
+    const int64_t nb = (int64_t)d->N * (2 * d->W + 2 * d->H) * (d->C / 4);
+    const int grid = (int)((nb + 255) / 256);
+    THIN_DISPATCH(thin_dgrad_border_kernel, a, dx, nb);
+  }
   return fmi_launch_status();
 }
 
