@@ -69,8 +69,60 @@ __global__ void __launch_bounds__(256) avgpool_bwd_kernel(const float* __restric
   }
 }
 
+// Global average pool (SEModule, helpers.py:56-72: AdaptiveAvgPool2d(1)): one output pixel per image.  The windowed kernel above
+// would give each thread a k*k-long strided walk; here 256 threads stream a slice of the image as float4 (consecutive threads =
+// consecutive channel chunks), combine through LDS and meet the other slices of the image through fp32 atomics (y zeroed first).
+__global__ void __launch_bounds__(256) global_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t HW, int C4,
+                                                            int64_t rows_per_block, float inv) {
+  __shared__ float4 part[256];
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4, RL = 256 / C4;
+  const int n = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > HW) r1 = HW;
+  const float4* xp = reinterpret_cast<const float4*>(x) + (int64_t)n * HW * C4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {
+    const float4 v0 = xp[r * C4 + cg], v1 = xp[(r + RL) * C4 + cg];
+    s.x += v0.x + v1.x; s.y += v0.y + v1.y; s.z += v0.z + v1.z; s.w += v0.w + v1.w;
+  }
+  for (; r < r1; r += RL) {
+    const float4 v = xp[r * C4 + cg];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float4 t = part[threadIdx.x];
+    for (int l = 1; l < RL; ++l) {
+      const float4 v = part[l * C4 + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float* o = y + ((int64_t)n * C4 + threadIdx.x) * 4;
+    atomicAdd(o + 0, t.x * inv);
+    atomicAdd(o + 1, t.y * inv);
+    atomicAdd(o + 2, t.z * inv);
+    atomicAdd(o + 3, t.w * inv);
+  }
+}
+
 extern "C" int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H / k <= 0 || W / k <= 0) return FMI_ERR_BAD_ARG;
+  {
+    const int C4 = C / 4;
+    if (k == H && k == W && k >= 8 && C % 4 == 0 && C4 <= 256 && (C4 & (C4 - 1)) == 0 && al16(x) && al16(y) && N <= 65535) {
+      const int64_t HW = (int64_t)H * W;
+      int64_t blocks = ceil_div64(HW, 128);
+      if (blocks * N > 2048) blocks = ceil_div64(2048, N);
+      const int64_t rpb = ceil_div64(HW, blocks);
+      blocks = ceil_div64(HW, rpb);
+      if (hipMemsetAsync(y, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream) != hipSuccess) return FMI_ERR_LAUNCH;
+      hipLaunchKernelGGL(global_avgpool_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, y, HW, C4, rpb,
+                         1.f / (float)HW);
+      return fmi_launch_status();
+    }
+  }
   const bool v4 = (C % 4 == 0) && al16(x) && al16(y);
   const int CV = v4 ? C / 4 : C;
   const int64_t total = (int64_t)N * (H / k) * (W / k) * CV;

@@ -520,3 +520,17 @@ def test_thin_output_conv(dev, FF, n, c, k, h, w, pad_mode, act):
         dx2 = torch.full((n, h, w, c), float("nan"), device=dev)
         lib.conv2d_dgrad_f32(C.byref(d), FF._p(gh), FF._p(wtp), None, None, FF._p(dx2), 1, 0, st)
         torch.testing.assert_close(dx2.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,h,c", [(3, 16, 64), (2, 64, 128), (16, 32, 512), (2, 8, 256), (2, 16, 12)])
+def test_global_average_pool(dev, FF, n, h, c):
+    """AdaptiveAvgPool2d(1) of the SE modules (helpers.py:56-72): reduction path (and the windowed fallback for C = 12)"""
+    g = torch.Generator().manual_seed(n * 100 + c)
+    x = torch.randn(n, h, h, c, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = FF.avg_pool(xd, h)
+    assert y.shape == (n, 1, 1, c)
+    torch.testing.assert_close(y.detach().cpu().view(n, c), x.mean(dim=(1, 2)), rtol=1e-5, atol=1e-6)
+    gy = torch.randn(n, 1, 1, c, generator=g)
+    y.backward(gy.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), (gy / (h * h)).expand(n, h, h, c), rtol=1e-6, atol=1e-8)
