@@ -53,10 +53,11 @@ static int conv_ksplit(int64_t M, int N, int K) {
 #ifdef FMI_HOST_EMU
   return 1;
 #else
-  const int64_t tiles = ceil_div64(M, 64) * ceil_div64(N, 128);
-  if (tiles >= 256 || K < 512) return 1;
-  int64_t ks = 512 / tiles;
-  if (ks > K / 192) ks = K / 192;
+  // keep the 128-wide tiles (operand reuse) and fill the chip by splitting the reduction instead of shrinking the tile
+  const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128));
+  if (tiles >= 320 || K < 512) return 1;
+  int64_t ks = ceil_div64(384, tiles);
+  if (ks > K / 256) ks = K / 256;  // at least 16 k-tiles per split
   return ks < 2 ? 1 : (int)(ks > 16 ? 16 : ks);
 #endif
 }
