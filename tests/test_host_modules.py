@@ -114,3 +114,36 @@ def test_psp_state_dict_keys_match_reference(golden):
     assert not any(p.requires_grad for p in net.decoder.parameters()) and all(p.requires_grad for p in net.encoder.parameters())
     with pytest.raises(Exception):
         pSp(types.SimpleNamespace(**{**vars(opts), "encoder_type": "nope"}))
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Error convention of the boundary: bad arguments come back as status codes before anything is launched --
+    null pointers, non-positive sizes, unsupported modes -- so this runs on a machine without a GPU."""
+    from face_mask_inpaint_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libfmi_hip.so not built")
+    c = ctypes.CDLL(_lib.LIB_PATH)
+    BAD, UNSUP = 1, 2
+    i64, f32, vp = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+    c.fmi_gemm_f32.argtypes = [vp, vp, vp] + [ctypes.c_int] * 3 + [i64] * 6 + [ctypes.c_int] + [i64] * 3 + [f32, f32, vp, vp]
+    assert c.fmi_gemm_f32(None, None, None, 4, 4, 4, 4, 1, 4, 1, 4, 1, 1, 0, 0, 0, 1.0, 0.0, None, None) == BAD
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, vp)
+    assert c.fmi_gemm_f32(p, p, p, 0, 4, 4, 4, 1, 4, 1, 4, 1, 1, 0, 0, 0, 1.0, 0.0, None, None) == BAD          # M = 0
+    assert c.fmi_gemm_f32(p, p, p, 4, 4, 4, 4, 2, 4, 1, 4, 1, 1, 0, 0, 0, 1.0, 0.0, None, None) == UNSUP        # A strided in both dims
+    d = _lib.ConvDesc(N=1, H=8, W=8, C=4, OH=8, OW=8, K=4, x_cstride=4, y_cstride=4, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    c.fmi_conv2d_fwd_f32.argtypes = [ctypes.POINTER(_lib.ConvDesc), vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, i64, vp]
+    assert c.fmi_conv2d_fwd_f32(ctypes.byref(d), None, p, None, None, p, 0, 1, 0, None) == BAD                 # x = NULL
+    assert c.fmi_conv2d_fwd_f32(ctypes.byref(d), p, p, None, None, p, 7, 1, 0, None) == BAD                    # unknown activation
+    d_bad = _lib.ConvDesc(N=1, H=8, W=8, C=4, OH=7, OW=8, K=4, x_cstride=4, y_cstride=4, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    assert c.fmi_conv2d_fwd_f32(ctypes.byref(d_bad), p, p, None, None, p, 0, 1, 0, None) != 0                  # OH inconsistent with H, pad, kh
+    c.fmi_conv2d_thin_supported.argtypes = [ctypes.POINTER(_lib.ConvDesc)]
+    assert c.fmi_conv2d_thin_supported(ctypes.byref(d)) == 1
+    d5 = _lib.ConvDesc(N=1, H=8, W=8, C=4, OH=8, OW=8, K=5, x_cstride=4, y_cstride=5, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    assert c.fmi_conv2d_thin_supported(ctypes.byref(d5)) == 0
+    c.fmi_upfirdn2d_f32.argtypes = [vp] * 3 + [ctypes.c_int] * 13 + [vp]
+    assert c.fmi_upfirdn2d_f32(p, p, p, 1, 4, 4, 4, 4, 0, 1, 1, 1, 0, 0, 0, 0, None) == BAD                     # up_x = 0
+    assert c.fmi_upfirdn2d_f32(p, p, p, 1, 2, 2, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == BAD                     # output would be empty
+    c.fmi_avgpool_f32.argtypes = [vp, vp] + [ctypes.c_int] * 5 + [vp]
+    assert c.fmi_avgpool_f32(p, p, 1, 4, 4, 4, 8, None) == BAD                                                 # window larger than the image
