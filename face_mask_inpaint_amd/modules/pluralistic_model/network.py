@@ -2,7 +2,7 @@
 ResEncoder / ResGenerator / ResDiscriminator networks with the reference's constructor arguments, attribute
 names (``block0``, ``encoder{i}``, ``infer_prior{i}``, ``prior`` / ``posterior``, ``generator``, ``decoder{i}``,
 ``out{i}``, ``attn{i}``, ``block1``, ``conv``) and forward signatures; all arithmetic runs in the HIP kernels.
-PatchDiscriminator (``--disc_model_type PatchDis``) is listed in SURVEY.md section 8f as a later widening.
+PatchDiscriminator (``--disc_model_type PatchDis``, network.py:373-430) is mirrored too.
 """
 from __future__ import annotations
 
@@ -30,9 +30,12 @@ def define_g(output_nc=3, ngf=64, z_nc=512, img_f=512, L=1, layers=5, norm="inst
 
 def define_d(input_nc=3, ndf=64, img_f=512, layers=6, norm="none", activation="LeakyReLU", use_spect=True, use_coord=False,
              use_attn=True, model_type="ResDis", init_type="orthogonal", gpu_ids=[]):
-    if model_type != "ResDis":
-        raise NotImplementedError("only the default ResDis discriminator is built so far (SURVEY.md 8f)")
-    net = ResDiscriminator(input_nc, ndf, img_f, layers, norm, activation, use_spect, use_coord, use_attn)
+    if model_type == "ResDis":
+        net = ResDiscriminator(input_nc, ndf, img_f, layers, norm, activation, use_spect, use_coord, use_attn)
+    elif model_type == "PatchDis":
+        net = PatchDiscriminator(input_nc, ndf, img_f, layers, norm, activation, use_spect, use_coord, use_attn)
+    else:
+        raise NotImplementedError("model_type %s" % model_type)
     return init_net(net, init_type, activation, gpu_ids)
 
 
@@ -181,6 +184,42 @@ class ResDiscriminator(nn.Module):
                 out = getattr(self, "encoder" + str(i)).nhwc(out)
             out = self.block1.nhwc(out)
             return run_conv(_conv(self.conv), FF.leaky_relu(out, self._slope))
+
+    def forward(self, x):
+        return FF.to_nchw(self.nhwc(FF.to_nhwc(x)))
+
+
+class PatchDiscriminator(nn.Module):
+    """network.py:373-430 (``--disc_model_type PatchDis``): ``layers`` 4x4 stride-2 SpectralNorm convs + two 4x4 stride-1 ones,
+    LeakyReLU in between, no bias, no norm layer (the reference builds ``norm_layer`` and never uses it).  ``model.N`` keys as in
+    the reference's nn.Sequential."""
+
+    def __init__(self, input_nc=3, ndf=64, img_f=512, layers=3, norm="batch", activation="LeakyReLU", use_spect=True, use_coord=False,
+                 use_attn=False):
+        super().__init__()
+        from .base_function import coord_conv
+
+        nonlinearity = get_nonlinearity_layer(activation_type=activation)
+        self._slope = _slope(nonlinearity)
+        kwargs = {"kernel_size": 4, "stride": 2, "padding": 1, "bias": False}
+        sequence = [coord_conv(input_nc, ndf, use_spect, use_coord, **kwargs), nonlinearity]
+        mult, i = 1, 0
+        for i in range(1, layers):
+            mult_prev = mult
+            mult = min(2 ** i, img_f // ndf)
+            sequence += [coord_conv(ndf * mult_prev, ndf * mult, use_spect, use_coord, **kwargs), nonlinearity]
+        mult_prev = mult
+        mult = min(2 ** i, img_f // ndf)
+        kwargs = {"kernel_size": 4, "stride": 1, "padding": 1, "bias": False}
+        sequence += [coord_conv(ndf * mult_prev, ndf * mult, use_spect, use_coord, **kwargs), nonlinearity,
+                     coord_conv(ndf * mult, 1, use_spect, use_coord, **kwargs)]
+        self.model = nn.Sequential(*sequence)
+
+    def nhwc(self, x):
+        with weight_scope(self):
+            for m in self.model:
+                x = FF.leaky_relu(x, self._slope) if isinstance(m, (nn.LeakyReLU, nn.ReLU)) else run_conv(_conv(m), x)
+            return x
 
     def forward(self, x):
         return FF.to_nchw(self.nhwc(FF.to_nhwc(x)))

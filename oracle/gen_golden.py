@@ -476,3 +476,24 @@ def psp_fixtures():
 
 if __name__ == "__main__":
     psp_fixtures()
+
+
+def patchdis_fixture():
+    """PatchDiscriminator (network.py:373-430), the --disc_model_type PatchDis alternative of row A8"""
+    ref_model, ref_loss, ref_network = import_reference()
+    torch.manual_seed(12)
+    g = torch.Generator().manual_seed(13)
+    d = ref_network.define_d(ndf=8, img_f=32, layers=3, norm="none", activation="LeakyReLU", model_type="PatchDis")
+    plain = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}  # sd_clone drops model.N.module.* as ResBlock aliases
+    sd0 = plain(d)
+    x = torch.randn(2, 3, 40, 36, generator=g, requires_grad=True)
+    y = d(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    torch.save(dict(sd0=sd0, sd1=plain(d), x=x.detach(), out=y.detach(), gout=gy, gx=x.grad.clone(),
+                    gparams={n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}), os.path.join(OUT, "picnet_patchdis.pt"))
+    print("patchdis: out", tuple(y.shape))
+
+
+if __name__ == "__main__":
+    patchdis_fixture()

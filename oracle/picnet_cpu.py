@@ -219,6 +219,18 @@ def res_discriminator(P: Params, prefix: str, x: torch.Tensor, layers: int = 5, 
 # ----------------------------------------------------------------------------
 # A1 / A7  mask prep, ReferenceFill.forward (model.py:10-12, 81-112)
 # ----------------------------------------------------------------------------
+def patch_discriminator(P: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """PatchDiscriminator.forward (network.py:373-430): model.0, 2, 4, ... are SpectralNorm 4x4 convs (stride 2, then two of stride 1),
+    LeakyReLU(0.1) between them, none after the last"""
+    idx = sorted({int(k[len(prefix) + len("model."):].split(".")[0]) for k in P if k.startswith(prefix + "model.") and k.endswith("weight_bar")})
+    for j, i in enumerate(idx):
+        stride = 2 if j < len(idx) - 2 else 1
+        x = sn_conv(P, f"{prefix}model.{i}", x, stride=stride, padding=1)
+        if j < len(idx) - 1:
+            x = lrelu(x)
+    return x
+
+
 def binarise_mask(mask_i64: torch.Tensor) -> torch.Tensor:
     """train_reference_fill.py:340  (mask > 0).float()"""
     return (mask_i64 > 0).float()

@@ -261,3 +261,19 @@ def test_psp_loss_oracle(golden):
         cx = O.vgg_loss(PV, "vgg", fx["y_hat"] * m, fx["ref"] * m, "contextual") * a["cx_lambda"]
     torch.testing.assert_close(st, fx["loss_dict"]["loss_style"].float(), rtol=1e-4, atol=1e-7)
     torch.testing.assert_close(cx, fx["loss_dict"]["loss_context"].float(), rtol=1e-4, atol=1e-7)
+
+
+def test_patch_discriminator_oracle(golden):
+    """--disc_model_type PatchDis (network.py:373-430), the alternative of row A8"""
+    fx = golden("picnet_patchdis.pt")
+    P = _params(fx["sd0"])
+    x = fx["x"].clone().requires_grad_(True)
+    y = O.patch_discriminator(P, "", x)
+    torch.testing.assert_close(y, fx["out"], **TOL)
+    y.backward(fx["gout"])
+    torch.testing.assert_close(x.grad, fx["gx"], rtol=1e-4, atol=1e-6)
+    for n, g in fx["gparams"].items():
+        torch.testing.assert_close(P[n].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m, n=n: f"{n}: {m}")
+    for k, v in fx["sd1"].items():
+        if k.endswith("weight_u") or k.endswith("weight_v"):
+            torch.testing.assert_close(P[k], v, **TOL)
