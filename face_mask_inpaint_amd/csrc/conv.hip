@@ -1,6 +1,7 @@
 // Implicit-GEMM convolution family: forward, adjoint (= ConvTranspose2d forward / conv input gradient)
 // and weight gradient.  See include/fmi_hip.h for the contract and gemm_core.h for the machine mapping.
 #include "gemm_core.h"
+#include "conv3x3.h"
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -81,6 +82,21 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
             (int64_t)d->OH * d->OW * d->y_cstride};
 #ifndef FMI_HOST_EMU
   const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
+  static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
+  const bool c3 = !c3_off && !(FMI_EXP & 32) && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0 &&
+                  conv3x3_eligible(x, wf, d->C, d->x_cstride, d->K, (int64_t)d->N * d->H * d->W);
+  if (c3) {
+    C3Args ca{x, wf, d->N, d->H, d->W, d->C, d->x_cstride, d->K, 0, make_fastdiv(d->W), make_fastdiv(d->H * d->W)};
+    if (ks > 1) {
+      const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
+      hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
+                         d->y_cstride, total);
+      ep.bias = nullptr;
+      ep.res = nullptr;
+      ep.act = 3;
+    }
+    return launch_conv3x3(ca, ep, g.Mdim(), ks, (hipStream_t)stream);
+  }
   if (ks > 1) {
     const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
     hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
@@ -131,6 +147,23 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
                 (int64_t)d->H * d->W * d->x_cstride};
 #ifndef FMI_HOST_EMU
       const int ks = (s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1;
+      static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
+      const bool c3 = !c3_off && !(FMI_EXP & 32) && s == 1 && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 &&
+                      conv3x3_eligible(dy, wt, d->K, d->y_cstride, d->C, (int64_t)d->N * d->H * d->W);
+      if (c3) {  // adjoint of a 3x3 stride-1 pad-1 convolution = the same convolution of dy with flipped taps
+        C3Args ca{dy, wt, d->N, d->OH, d->OW, d->K, d->y_cstride, d->C, 1, make_fastdiv(d->OW), make_fastdiv(d->OH * d->OW)};
+        if (ks > 1) {
+          const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
+          hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
+                             d->C, d->x_cstride, total);
+          ep.bias = nullptr;
+          ep.res = nullptr;
+          ep.act = 3;
+        }
+        rc = launch_conv3x3(ca, ep, g.Mdim(), ks, (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
       if (ks > 1) {
         const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
         hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
