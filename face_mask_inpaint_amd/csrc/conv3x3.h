@@ -160,10 +160,11 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
   store_tile<ConvEp, T>(ep, acc, M, a.Nout, m0 + wm, n0 + wn, lh, l31);
 }
 
-// geometry the tap-reuse kernel takes (the caller falls back to the generic path otherwise).  C >= 64: with 32 reduction channels a
-// tile has only 6 k-steps and the heavier prologue loses (measured: 52 -> 42 TFLOP/s at 8 x 128^2, 32 -> 64)
+// geometry the tap-reuse kernel takes (the caller falls back to the generic path otherwise).  C >= 64 or a narrow output: with 32
+// reduction channels a tile has only 6 k-steps and, for 64 outputs, the heavier prologue loses (52 -> 42 TFLOP/s at 8 x 128^2, 32 -> 64)
+// while 32 -> 32 still gains (71 -> 81)
 static bool conv3x3_eligible(const float* x, const float* w, int C, int cs, int Nout, int64_t pixels) {
-  return (C & 15) == 0 && C >= 64 && (cs & 3) == 0 && (Nout & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && pixels < (1ll << 30);
+  return (C & 15) == 0 && (C >= 64 || Nout <= 32) && (cs & 3) == 0 && (Nout & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && pixels < (1ll << 30);
 }
 
 static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, hipStream_t st) {
