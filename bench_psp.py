@@ -77,6 +77,38 @@ def decoder_profile(size, n, dev, backward=True):
     return summarise(recs)
 
 
+def native_op_bandwidth(dev):
+    """the reference's two native ops through their drop-in python names, planar [N*C, H, W] layout, fp32 and bf16, at the Blur shape
+    of the 1024^2 decoder (4 images x 32 channels, 1025^2 -> 1024^2) and a 512^2 x 64 activation for the fused bias+lrelu"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op.fused_act import fused_bias_act
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op.upfirdn2d import _native
+
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k = (k[None, :] * k[:, None] / 64 * 4).to(dev)
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = torch.randn(128, 1025, 1025, device=dev).to(dt)
+        a = torch.randn(4, 64, 512, 512, device=dev).to(dt)
+        b = torch.randn(64, device=dev).to(dt)
+        empty = a.new_empty(0)
+        res = {}
+        for key, fn, nbytes in (("upfirdn2d", lambda: _native(x, k, 1, 1, 1, 1, 1, 1, 1, 1), (128 * 1025 * 1025 + 128 * 1024 * 1024) * x.element_size()),
+                                ("fused_bias_act", lambda: fused_bias_act(a, b, empty, 3, 0, 0.2, 2 ** 0.5), 2 * a.numel() * a.element_size())):
+            for _ in range(2):
+                fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(5):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / 5
+            res[key] = {"ms": round(ms, 3), "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        out[name] = res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -129,6 +161,7 @@ def main():
            "n_gpus": 1, "batch": args.batch, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 2), "dtype": "f32", "data": "synthetic",
            "whole_step": whole,
            "decoder_256_fwd_bwd": decoder_profile(256, args.batch, dev),
+           "native_ops_planar": native_op_bandwidth(dev),
            "peaks": {"fp32_mfma_tflops": FP32_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}}
     if not args.skip_1024:
         out["decoder_1024_fwd_bs4"] = decoder_profile(1024, 4, dev, backward=False)

@@ -223,14 +223,24 @@ extern "C" int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const
 }
 
 // ---- the reference's fused_bias_act (NCHW contiguous; op/fused_bias_act_kernel.cu:36-47 semantics) ----
-__global__ void __launch_bounds__(256) fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
-                                                             const float* __restrict__ ref, float* __restrict__ out,
+__device__ __forceinline__ float fba_ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float fba_ld(const uint16_t* p, int64_t i) { return __uint_as_float((uint32_t)p[i] << 16); }
+__device__ __forceinline__ void fba_st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void fba_st(uint16_t* p, int64_t i, float v) {  // bf16, round to nearest even
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
+  else u += 0x7fffu + ((u >> 16) & 1u);
+  p[i] = (uint16_t)(u >> 16);
+}
+template <class T>
+__global__ void __launch_bounds__(256) fused_bias_act_kernel(const T* __restrict__ x, const T* __restrict__ bias,
+                                                             const T* __restrict__ ref, T* __restrict__ out,
                                                              int64_t n, int step_b, int size_b, int act, int grad,
                                                              float alpha, float scale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float v = x[i];
-    if (bias) v += bias[(i / step_b) % size_b];
-    const float r = ref ? ref[i] : 0.f;
+    float v = fba_ld(x, i);
+    if (bias) v += fba_ld(bias, (i / step_b) % size_b);
+    const float r = ref ? fba_ld(ref, i) : 0.f;
     float y;
     if (act == 3) {
       if (grad == 0) y = v > 0.f ? v : v * alpha;
@@ -239,17 +249,64 @@ __global__ void __launch_bounds__(256) fused_bias_act_kernel(const float* __rest
     } else {
       y = grad == 2 ? 0.f : v;
     }
-    out[i] = y * scale;
+    fba_st(out, i, y * scale);
   }
 }
-extern "C" int fmi_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* out, int64_t n, int step_b,
-                                      int size_b, int act, int grad, float alpha, float scale, void* stream) {
+// 16-byte vector form: V consecutive elements share a bias entry when step_b % V == 0
+template <class T, int V>
+__global__ void __launch_bounds__(256) fused_bias_act_vec_kernel(const T* __restrict__ x, const T* __restrict__ bias,
+                                                                 const T* __restrict__ ref, T* __restrict__ out, int64_t nv, int step_b,
+                                                                 int size_b, int act, int grad, float alpha, float scale) {
+  struct alignas(16) Pack {
+    T e[V];
+  };
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const Pack px = reinterpret_cast<const Pack*>(x)[i];
+    Pack pr = px, po;
+    if (ref) pr = reinterpret_cast<const Pack*>(ref)[i];
+    const float b = bias ? fba_ld(bias, ((i * V) / step_b) % size_b) : 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float v = fba_ld(px.e, j) + b;
+      const float r = ref ? fba_ld(pr.e, j) : 0.f;
+      float y;
+      if (act == 3) {
+        if (grad == 0) y = v > 0.f ? v : v * alpha;
+        else if (grad == 1) y = r > 0.f ? v : v * alpha;
+        else y = 0.f;
+      } else {
+        y = grad == 2 ? 0.f : v;
+      }
+      fba_st(po.e, j, y * scale);
+    }
+    reinterpret_cast<Pack*>(out)[i] = po;
+  }
+}
+
+template <class T>
+static int fused_bias_act_launch(const T* x, const T* bias, const T* ref, T* out, int64_t n, int step_b, int size_b, int act, int grad,
+                                 float alpha, float scale, void* stream) {
   if (!x || !out || n <= 0) return FMI_ERR_BAD_ARG;
   if (bias && (step_b <= 0 || size_b <= 0)) return FMI_ERR_BAD_ARG;
   if ((act != 1 && act != 3) || grad < 0 || grad > 2) return FMI_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fused_bias_act_kernel, dim3(fmi_bw_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, bias, ref, out, n,
+  constexpr int V = 16 / (int)sizeof(T);
+  const bool al = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)(ref ? ref : x)) & 15) == 0);
+  if (al && n % V == 0 && (!bias || step_b % V == 0)) {
+    hipLaunchKernelGGL((fused_bias_act_vec_kernel<T, V>), dim3(fmi_bw_grid(n / V, 256)), dim3(256), 0, (hipStream_t)stream, x, bias, ref, out,
+                       n / V, step_b, size_b, act, grad, alpha, scale);
+    return fmi_launch_status();
+  }
+  hipLaunchKernelGGL((fused_bias_act_kernel<T>), dim3(fmi_bw_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, bias, ref, out, n,
                      step_b, size_b, act, grad, alpha, scale);
   return fmi_launch_status();
+}
+extern "C" int fmi_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* out, int64_t n, int step_b,
+                                      int size_b, int act, int grad, float alpha, float scale, void* stream) {
+  return fused_bias_act_launch<float>(x, bias, ref, out, n, step_b, size_b, act, grad, alpha, scale, stream);
+}
+extern "C" int fmi_fused_bias_act_bf16(const uint16_t* x, const uint16_t* bias, const uint16_t* ref, uint16_t* out, int64_t n, int step_b,
+                                       int size_b, int act, int grad, float alpha, float scale, void* stream) {
+  return fused_bias_act_launch<uint16_t>(x, bias, ref, out, n, step_b, size_b, act, grad, alpha, scale, stream);
 }
 
 // NHWC variant for StyledConv (stylegan2/model.py:340-346): y = lrelu(x + bias[c] + nw*noise[p]) * scale

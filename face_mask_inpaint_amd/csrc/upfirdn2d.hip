@@ -20,13 +20,25 @@ __device__ __forceinline__ int floordiv(int a, int b) {
   return q;
 }
 
+// element types: fp32, or bf16 stored as uint16_t (arithmetic is fp32 either way, results rounded to nearest even)
+__device__ __forceinline__ float uf_ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float uf_ld(const uint16_t* p, int64_t i) { return __uint_as_float((uint32_t)p[i] << 16); }
+__device__ __forceinline__ void uf_st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void uf_st(uint16_t* p, int64_t i, float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;      // quiet NaN keeps its payload bit
+  else u += 0x7fffu + ((u >> 16) & 1u);                        // round to nearest even
+  p[i] = (uint16_t)(u >> 16);
+}
+
 struct UfParams {
   int major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
   int tile_in_h, tile_in_w, tiles_x, tiles_y;
 };
 
-__global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ in, const float* __restrict__ kernel,
-                                                        float* __restrict__ out, UfParams p) {
+template <class T>
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const T* __restrict__ in, const T* __restrict__ kernel,
+                                                        T* __restrict__ out, UfParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sk = smem;                 // [kh][kw] flipped taps
   float* sx = smem + p.kh * p.kw;   // [tile_in_h][tile_in_w]
@@ -42,18 +54,18 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
   const int ix0 = floordiv(ox0 * p.down_x - p.pad_x0, p.up_x);
   for (int t = tid; t < p.kh * p.kw; t += 256) {
     const int ky = t / p.kw, kx = t - ky * p.kw;
-    sk[t] = kernel[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+    sk[t] = uf_ld(kernel, (p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx));
   }
-  const float* ip = in + (int64_t)plane * p.in_h * p.in_w;
+  const T* ip = in + (int64_t)plane * p.in_h * p.in_w;
   for (int t = tid; t < p.tile_in_h * p.tile_in_w; t += 256) {
     const int ry = t / p.tile_in_w, rx = t - ry * p.tile_in_w;
     const int iy = iy0 + ry, ix = ix0 + rx;
     float v = 0.f;
-    if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) v = ip[(int64_t)iy * p.in_w + ix];
+    if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) v = uf_ld(ip, (int64_t)iy * p.in_w + ix);
     sx[t] = v;
   }
   __syncthreads();
-  float* op = out + (int64_t)plane * p.out_h * p.out_w;
+  T* op = out + (int64_t)plane * p.out_h * p.out_w;
   const int lx = tid & (UF_TW - 1);
   const int ox = ox0 + lx;
   if (ox >= p.out_w) return;
@@ -76,13 +88,75 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
         acc += sx[ry * p.tile_in_w + rx] * sk[ky * p.kw + kx];
       }
     }
-    op[(int64_t)oy * p.out_w + ox] = acc;
+    uf_st(op, (int64_t)oy * p.out_w + ox, acc);
   }
 }
 
-extern "C" int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w, int kh,
-                                 int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
-                                 int pad_y1, void* stream) {
+
+// FIR-only fast path (up = down = 1: the Blur of every up-convolution and its gradients -- all of the op's traffic at 1024^2):
+// 32 x 64 output tile per workgroup, the (32+KH-1) x (64+KW-1) input window staged once in LDS; a thread owns one column and 8
+// rows and slides down it: each staged row is read once (KW values) and feeds the up to KH outputs it touches, taps are
+// compile-time.  5.5 LDS reads per output instead of 16 + the modulo arithmetic of the generic poly-phase loop.
+#define FIR_TH 32
+#define FIR_TW 64
+template <class T, int KH, int KW>
+__global__ void __launch_bounds__(256) upfirdn2d_fir_kernel(const T* __restrict__ in, const T* __restrict__ kernel, T* __restrict__ out,
+                                                            UfParams p) {
+  constexpr int IH = FIR_TH + KH - 1, IW = FIR_TW + KW - 1, LDW = IW + 1;
+  __shared__ float sx[IH * LDW];
+  float kf[KH][KW];  // flipped taps: out[y][x] = sum_{a,b} in[y - pad_y0 + a][x - pad_x0 + b] * kernel[KH-1-a][KW-1-b]
+#pragma unroll
+  for (int a = 0; a < KH; ++a)
+#pragma unroll
+    for (int b = 0; b < KW; ++b) kf[a][b] = uf_ld(kernel, (KH - 1 - a) * KW + (KW - 1 - b));
+  const int tid = threadIdx.x;
+  int b_ = blockIdx.x;
+  const int tx = b_ % p.tiles_x;
+  b_ /= p.tiles_x;
+  const int ty = b_ % p.tiles_y;
+  const int plane = b_ / p.tiles_y;
+  const int oy0 = ty * FIR_TH, ox0 = tx * FIR_TW;
+  const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
+  const T* ip = in + (int64_t)plane * p.in_h * p.in_w;
+  for (int t = tid; t < IH * IW; t += 256) {
+    const int ry = t / IW, rx = t - ry * IW;
+    const int iy = iy0 + ry, ix = ix0 + rx;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)p.in_h && (unsigned)ix < (unsigned)p.in_w) v = uf_ld(ip, (int64_t)iy * p.in_w + ix);
+    sx[ry * LDW + rx] = v;
+  }
+  __syncthreads();
+  const int lx = tid & (FIR_TW - 1), ly0 = (tid >> 6) * 8;
+  const int ox = ox0 + lx;
+  if (ox >= p.out_w) return;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8 + KH - 1; ++r) {  // staged row ly0 + r feeds output rows r - a (a = tap row)
+    float v[KW];
+#pragma unroll
+    for (int b = 0; b < KW; ++b) v[b] = sx[(ly0 + r) * LDW + lx + b];
+#pragma unroll
+    for (int a = 0; a < KH; ++a) {
+      const int o = r - a;
+      if (o >= 0 && o < 8) {
+#pragma unroll
+        for (int b = 0; b < KW; ++b) acc[o] = fmaf(v[b], kf[a][b], acc[o]);
+      }
+    }
+  }
+  T* op = out + (int64_t)plane * p.out_h * p.out_w;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int oy = oy0 + ly0 + r;
+    if (oy < p.out_h) uf_st(op, (int64_t)oy * p.out_w + ox, acc[r]);
+  }
+}
+
+template <class T>
+static int upfirdn2d_launch(const T* in, const T* kernel, T* out, int major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                            int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
   if (!in || !kernel || !out || major <= 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0) return FMI_ERR_BAD_ARG;
   if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return FMI_ERR_BAD_ARG;
   UfParams p;
@@ -92,6 +166,17 @@ extern "C" int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* ou
   if (full_h < 0 || full_w < 0) return FMI_ERR_BAD_ARG;
   p.out_h = full_h / down_y + 1;
   p.out_w = full_w / down_x + 1;
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4) {
+    p.tile_in_h = p.tile_in_w = 0;
+    p.tiles_x = (p.out_w + FIR_TW - 1) / FIR_TW;
+    p.tiles_y = (p.out_h + FIR_TH - 1) / FIR_TH;
+    const int64_t nb = (int64_t)major * p.tiles_x * p.tiles_y;
+    if (nb > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+    if (kh == 4) hipLaunchKernelGGL((upfirdn2d_fir_kernel<T, 4, 4>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    else if (kh == 3) hipLaunchKernelGGL((upfirdn2d_fir_kernel<T, 3, 3>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    else hipLaunchKernelGGL((upfirdn2d_fir_kernel<T, 2, 2>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    return fmi_launch_status();
+  }
   // input rows touched by a tile: up-sampled extent (TH-1)*down + kh, i.e. at most that / up + 2 samples
   p.tile_in_h = ((UF_TH - 1) * down_y + kh - 1) / up_y + 2;
   p.tile_in_w = ((UF_TW - 1) * down_x + kw - 1) / up_x + 2;
@@ -101,6 +186,17 @@ extern "C" int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* ou
   p.tiles_y = (p.out_h + UF_TH - 1) / UF_TH;
   const int64_t blocks = (int64_t)major * p.tiles_x * p.tiles_y;
   if (blocks > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, in, kernel, out, p);
+  hipLaunchKernelGGL((upfirdn2d_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, in, kernel, out, p);
   return fmi_launch_status();
+}
+
+extern "C" int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w, int kh,
+                                 int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                 int pad_y1, void* stream) {
+  return upfirdn2d_launch<float>(in, kernel, out, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+extern "C" int fmi_upfirdn2d_bf16(const uint16_t* in, const uint16_t* kernel, uint16_t* out, int major, int in_h, int in_w, int kh,
+                                  int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                                  int pad_y1, void* stream) {
+  return upfirdn2d_launch<uint16_t>(in, kernel, out, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
 }

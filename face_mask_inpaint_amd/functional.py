@@ -97,14 +97,14 @@ def _p(t: Optional[torch.Tensor], off: int = 0):
     return C.c_void_p(t.data_ptr() + 4 * off)
 
 
-def _chk(*ts):
+def _chk(*ts, dtype=torch.float32):
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise FmiError("face_mask_inpaint_amd ops need device tensors (there is no CPU fallback)")
-        if t.dtype != torch.float32:
-            raise FmiError(f"expected float32, got {t.dtype}")
+        if t.dtype != dtype:
+            raise FmiError(f"expected {dtype}, got {t.dtype}")
         if not t.is_contiguous():
             raise FmiError("expected a contiguous tensor")
 

@@ -15,14 +15,18 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     x = input.contiguous()
     b = bias.contiguous() if bias is not None and bias.numel() else None
     r = refer.contiguous() if refer is not None and refer.numel() else None
-    _chk(x, b, r)
+    bf16 = x.dtype == torch.bfloat16
+    if bf16:
+        b = b.to(torch.bfloat16) if b is not None else None
+        r = r.to(torch.bfloat16) if r is not None else None
+    _chk(x, b, r, dtype=x.dtype if bf16 else torch.float32)
     step_b = 1
     for d in x.shape[2:]:
         step_b *= d
     y = torch.empty_like(x)
     if x.numel():
-        _lib.lib().fused_bias_act_f32(_p(x), _p(b), _p(r), _p(y), x.numel(), step_b, b.numel() if b is not None else 1, act, grad,
-                                      float(alpha), float(scale), _st())
+        fn = _lib.lib().fused_bias_act_bf16 if bf16 else _lib.lib().fused_bias_act_f32
+        fn(_p(x), _p(b), _p(r), _p(y), x.numel(), step_b, b.numel() if b is not None else 1, act, grad, float(alpha), float(scale), _st())
     return y
 
 

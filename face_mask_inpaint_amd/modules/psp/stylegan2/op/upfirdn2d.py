@@ -1,6 +1,6 @@
 """Host-side mirror of modules/psp/stylegan2/op/upfirdn2d.py: ``upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))``
-with first- and second-order autograd, on the HIP kernel ``fmi_upfirdn2d_f32`` (no JIT build at import, any
-up/down/kernel size).  ``upfirdn2d_native`` of the reference is test infrastructure there and lives in oracle/ here."""
+with first- and second-order autograd, on the HIP kernels ``fmi_upfirdn2d_f32`` / ``fmi_upfirdn2d_bf16`` (no JIT build at
+import, any up/down/kernel size; bf16 tensors are filtered in fp32 and rounded to nearest even).  ``upfirdn2d_native`` of the reference is test infrastructure there and lives in oracle/ here."""
 from __future__ import annotations
 
 import ctypes as C
@@ -14,16 +14,19 @@ from .....functional import FmiError, _chk, _p, _st
 
 def _native(x_planes, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """the reference's pybind entry (op/upfirdn2d.cpp:12-23) for minor = 1: [major,H,W] -> [major,OH,OW]"""
-    _chk(x_planes, kernel)
+    bf16 = x_planes.dtype == torch.bfloat16  # the reference's op is dispatched on the tensor dtype, taps included
+    if bf16:
+        kernel = kernel.to(torch.bfloat16)
+    _chk(x_planes, kernel, dtype=x_planes.dtype if bf16 else torch.float32)
     major, in_h, in_w = x_planes.shape
     kh, kw = kernel.shape
     out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
     out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
     if out_h <= 0 or out_w <= 0:
         raise FmiError("upfirdn2d: empty output")
-    out = torch.empty((major, out_h, out_w), device=x_planes.device, dtype=torch.float32)
-    _lib.lib().upfirdn2d_f32(_p(x_planes), _p(kernel), _p(out), major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y,
-                             pad_x0, pad_x1, pad_y0, pad_y1, _st())
+    out = torch.empty((major, out_h, out_w), device=x_planes.device, dtype=x_planes.dtype)
+    fn = _lib.lib().upfirdn2d_bf16 if bf16 else _lib.lib().upfirdn2d_f32
+    fn(_p(x_planes), _p(kernel), _p(out), major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, _st())
     return out
 
 

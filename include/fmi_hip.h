@@ -283,11 +283,17 @@ int fmi_adam_step_f32(const fmi_adam_entry* entries /* HOST array */, int count,
 int fmi_upfirdn2d_f32(const float* in, const float* kernel, float* out, int major, int in_h, int in_w,
                       int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                       int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* bf16 storage (uint16_t bit patterns), fp32 arithmetic, round-to-nearest-even results: the reference's op is templated on the
+ * tensor dtype (op/upfirdn2d_kernel.cu:149-170 AT_DISPATCH), taps included */
+int fmi_upfirdn2d_bf16(const uint16_t* in, const uint16_t* kernel, uint16_t* out, int major, int in_h, int in_w, int kh, int kw,
+                       int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 /* x [.., C, step_b...] contiguous NCHW as in the reference: bias index = (i / step_b) % size_b.
  * act: 1 linear, 3 leaky relu; grad: 0 forward, 1 first derivative w.r.t. x using ref = forward OUTPUT, 2 second (=0).
  * bias / ref may be NULL. */
 int fmi_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* out, int64_t n,
                            int step_b, int size_b, int act, int grad, float alpha, float scale, void* stream);
+int fmi_fused_bias_act_bf16(const uint16_t* x, const uint16_t* bias, const uint16_t* ref, uint16_t* out, int64_t n, int step_b,
+                            int size_b, int act, int grad, float alpha, float scale, void* stream);
 /* dbias[c] += sum_{n,hw} g[n][c][hw] for NCHW g (grad_bias of FusedLeakyReLU, op/fused_act.py:29-36); caller zeroes dbias */
 int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream);
 /* NHWC variant used by the product's StyledConv: y = lrelu(x + bias[c] + nw[0]*noise[p]) * scale */

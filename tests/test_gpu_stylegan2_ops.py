@@ -202,3 +202,41 @@ def test_upfirdn2d_nhwc_vector_and_generic_paths(dev):
         torch.testing.assert_close(got.detach().cpu().permute(0, 3, 1, 2), want.detach(), rtol=1e-5, atol=1e-5, msg=lambda m: f"{(n, h, w, c, up, down, pad)}: {m}")
         got.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
         torch.testing.assert_close(xd.grad.cpu().permute(0, 3, 1, 2), gx_want, rtol=1e-5, atol=1e-5, msg=lambda m: f"grad {(n, h, w, c, up, down, pad)}: {m}")
+
+
+def test_native_ops_bf16(dev, golden):
+    """bf16 storage variants of the two native ops (BASELINE configs[2]/[4] run the decoder in bf16): inputs rounded to bf16, fp32
+    arithmetic, result rounded to nearest even -- against the C oracle on the same rounded inputs, within one bf16 ulp"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op import fused_leaky_relu, upfirdn2d
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op.fused_act import fused_bias_act
+    from oracle import stylegan2_cpu as S  # checker
+
+    def close_bf16(got, want):
+        got, want = got.float().cpu(), want.float()
+        tol = want.abs() * 2 ** -7 + 1e-6  # one ulp of bf16 (8 significant bits)
+        assert ((got - want).abs() <= tol).all(), float(((got - want).abs() - tol).max())
+
+    g = torch.Generator().manual_seed(31)
+    k4 = S.make_kernel([1, 3, 3, 1]) * 4
+    for shape, up, down, pad in (((2, 6, 17, 17), 1, 1, (1, 1)), ((2, 3, 16, 16), 2, 1, (2, 1)), ((1, 4, 33, 30), 1, 2, (1, 1)), ((2, 5, 9, 8), 1, 1, (2, 1))):
+        x = torch.randn(*shape, generator=g).to(torch.bfloat16)
+        kb = k4.to(torch.bfloat16)
+        want = S.upfirdn2d(x.float(), kb.float(), up, down, pad).to(torch.bfloat16)
+        got = upfirdn2d(x.to(dev), k4.to(dev), up=up, down=down, pad=pad)
+        assert got.dtype == torch.bfloat16 and got.shape == want.shape
+        close_bf16(got, want)
+    x = torch.randn(2, 6, 5, 4, generator=g).to(torch.bfloat16)
+    b = torch.randn(6, generator=g).to(torch.bfloat16)
+    want = (torch.nn.functional.leaky_relu(x.float() + b.float().view(1, -1, 1, 1), 0.2) * 2 ** 0.5).to(torch.bfloat16)
+    got = fused_bias_act(x.to(dev), b.to(dev), x.new_empty(0).to(dev), 3, 0, 0.2, 2 ** 0.5)
+    assert got.dtype == torch.bfloat16
+    close_bf16(got, want)
+    ref = torch.randn(2, 6, 5, 4, generator=g).to(torch.bfloat16)
+    got = fused_bias_act(x.to(dev), x.new_empty(0).to(dev), ref.to(dev), 3, 1, 0.2, 2 ** 0.5)  # gradient form
+    want = (torch.where(ref.float() > 0, x.float(), x.float() * 0.2) * 2 ** 0.5).to(torch.bfloat16)
+    close_bf16(got, want)
+    # bandwidth at the 1024^2 decoder's Blur shape: 4 images x 32 channels, 1025^2 -> 1024^2, bf16
+    xb = torch.randn(4 * 32, 1025, 1025, device=dev).to(torch.bfloat16)
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op.upfirdn2d import _native
+    y = _native(xb, k4.to(dev), 1, 1, 1, 1, 1, 1, 1, 1)
+    assert y.shape == (128, 1024, 1024) and torch.isfinite(y.float()).all()
