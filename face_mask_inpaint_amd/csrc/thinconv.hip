@@ -13,6 +13,7 @@
 //   wgrad   : per-lane accumulators [9][4][K] over a strided range of pixels, reduced over the wave's pixel groups by
 //             shuffles, over the workgroup's waves through LDS, over workgroups by fp32 atomics; dbias rides along.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -304,6 +305,83 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(ThinArgs a, int qbit
   }
 }
 
+
+// Forward with an LDS-staged halo tile (C = 32): a workgroup owns 8 x 32 output pixels, reads the 10 x 34 input window ONCE with
+// fully coalesced 16-byte loads (8 consecutive lanes = one pixel's 128 bytes; the texture path is paced per wave instruction and
+// the gather of the row-segment kernel above -- 4 pixels x 16 B per MFMA block, 128 B apart -- costs it ~4x as many cycles per byte),
+// then every tap comes out of LDS as ds_read_b128 in the MFMA block layout.  Input bytes cross HBM/L2 1.33x instead of 9x.
+constexpr int LT_H = 8, LT_W = 32, LT_PITCH = 36;  // pixel pitch in floats (32 channels + 4 pad: spreads the b128 reads over the banks)
+template <int K>
+__global__ void __launch_bounds__(256) thin_fwd_lds_kernel(ThinArgs a, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float sx[(LT_H + 2) * (LT_W + 2) * LT_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 3, q = (lane >> 2) & 7, g = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x;
+  b /= tiles_x;
+  const int ty = b % tiles_y, n = b / tiles_y;
+  const int y0 = ty * LT_H, x0 = tx * LT_W;
+  float wr[9][4];  // A operand: w[t][4q+e][k = i]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)t * a.C + 4 * q + e) * K + i] : 0.f;
+  // stage the window: chunk c8 = tid & 7 of window pixel (tid >> 3) + 32 j
+  const float* img = a.x + (int64_t)n * a.H * a.W * a.xcs;
+  constexpr int NPIX = (LT_H + 2) * (LT_W + 2), NLD = (NPIX + 31) / 32;
+  float4 stage[NLD];  // all loads in flight before the first LDS store (a load-store-load chain would pay the latency NLD times)
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int p = (tid >> 3) + 32 * j;
+    const int wy = p / (LT_W + 2), wx = p - wy * (LT_W + 2);
+    int iy = y0 + wy - 1, ix = x0 + wx - 1;
+    if (a.pad_mode) {
+      iy = reflect1(iy, a.H);
+      ix = reflect1(ix, a.W);
+    }
+    const bool ok = p < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) stage[j] = *reinterpret_cast<const float4*>(img + ((int64_t)iy * a.W + ix) * a.xcs + 4 * (tid & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int p = (tid >> 3) + 32 * j;
+    if (p < NPIX) *reinterpret_cast<float4*>(sx + p * LT_PITCH + 4 * (tid & 7)) = stage[j];
+  }
+  __syncthreads();
+  // wave `wid` owns tile rows 2*wid, 2*wid+1; an iteration = 8 consecutive pixels of a row (2 groups x 4)
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int ly = 2 * wid + (it >> 2), lx = (it & 3) * 8 + g * 4 + i;
+    const float* base = sx + (ly * (LT_W + 2) + lx) * LT_PITCH + 4 * q;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4 v = *reinterpret_cast<const float4*>(base + ((t / 3) * (LT_W + 2) + (t % 3)) * LT_PITCH);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][0], v.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][1], v.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][2], v.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][3], v.w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 4; m < 32; m <<= 1)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+    const int oy = y0 + ly, ox = x0 + lx;
+    if (q < K && oy < a.H && ox < a.W) {  // after the reduction every chunk lane holds the totals: lane q finishes channel q
+      const int64_t o = ((int64_t)(n * a.H + oy) * a.W + ox) * a.ycs + q;
+      float r = acc[0];
+#pragma unroll
+      for (int k = 1; k < K; ++k) r = q == k ? acc[k] : r;
+      if (a.bias) r += a.bias[q];
+      if (a.res) r += a.res[o];
+      if (a.act == 1) r = tanhf(r);
+      else if (a.act == 2) r = fmaxf(r, 0.f);
+      a.y[o] = r;
+    }
+  }
+}
+
 // adjoint with ZERO padding semantics: per-lane quantity = the pixel (B operand = dy of the pixels whose windows cover it), A operand =
 // w[t][4q + r][k]; lane (g, q, i) ends with dx[pixel][4q .. 4q+3] in its accumulator: one 16-byte store.  (Reflect padding: the
 // caller re-computes the two border rows / columns with thin_dgrad_border_kernel, which knows the fold.)
@@ -342,9 +420,14 @@ __global__ void __launch_bounds__(256) thin_dgrad_mfma_kernel(ThinArgs a, float*
         if (!cok) px = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          const float* gq = gp[r] + px * a.ycs;
+          // ONE K-dword load per tap (global_load_dwordx3 for K = 3): the texture path is paced per wave instruction, and the 8
+          // lanes of a pixel group all read the same address -- 27 single-dword loads per step were the kernel's bottleneck
+          struct __attribute__((packed, aligned(4))) GK {
+            float e[K];
+          };
+          const GK g = *reinterpret_cast<const GK*>(gp[r] + px * a.ycs);
 #pragma unroll
-          for (int k = 0; k < K; ++k) gv[r * 3 + c][k] = (cok && rok[r]) ? gq[k] : 0.f;
+          for (int k = 0; k < K; ++k) gv[r * 3 + c][k] = (cok && rok[r]) ? g.e[k] : 0.f;
         }
       }
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -387,6 +470,15 @@ extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, c
   if (total >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
   int qbits = 0;
   while ((1 << qbits) < G) ++qbits;
+  if (d->C == 32 && !getenv("FMI_THIN_NO_LDS")) {  // halo tile through LDS
+    const int tiles_x = (d->W + LT_W - 1) / LT_W, tiles_y = (d->H + LT_H - 1) / LT_H;
+    const int64_t nb = (int64_t)d->N * tiles_x * tiles_y;
+    if (nb < (1ll << 31)) {
+      const int grid = (int)nb;
+      THIN_DISPATCH(thin_fwd_lds_kernel, a, tiles_x, tiles_y);
+      return fmi_launch_status();
+    }
+  }
   const int segs = (d->W + SEG - 1) / SEG, ntasks = d->N * d->H * segs;
   const int grid = ntasks / 4 > 8192 ? 8192 : (ntasks + 3) / 4;
   THIN_DISPATCH(thin_fwd_mfma_kernel, a, qbits, ntasks, segs);

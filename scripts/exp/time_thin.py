@@ -17,6 +17,8 @@ def timeit(fn, nrep=5):
 for path in sys.argv[1:]:
     lib = _lib.Library(path)
     tf = timeit(lambda: lib.conv2d_thin_fwd_f32(C.byref(d), FF._p(x), FF._p(wf), None, None, FF._p(y), 1, st))
+    tf0 = timeit(lambda: lib.conv2d_thin_fwd_f32(C.byref(d), FF._p(x), FF._p(wf), None, None, FF._p(y), 0, st))
+    print("   forward without tanh: %.3f ms" % tf0)
     td = timeit(lambda: lib.conv2d_thin_dgrad_f32(C.byref(d), FF._p(gy), FF._p(wt), FF._p(gx), st))
     tw = timeit(lambda: lib.conv2d_thin_wgrad_f32(C.byref(d), FF._p(x), FF._p(gy), FF._p(gw), FF._p(gb), st))
     gb_ = x.numel() * 4 / 1e9
