@@ -382,6 +382,117 @@ __global__ void __launch_bounds__(256) thin_fwd_lds_kernel(ThinArgs a, int tiles
   }
 }
 
+
+// Weight gradient with the same LDS halo tile: persistent workgroups walk the 8 x 32 tiles, x comes out of LDS (ds_read_b128, lane =
+// (pixel group, 4-channel chunk) as in thin_wgrad_kernel), dy as one K-dword load per pixel; the [9][4][K] accumulators live in
+// registers across all tiles of the workgroup and are reduced once at the end.
+template <int K>
+__global__ void __launch_bounds__(256) thin_wgrad_lds_kernel(ThinArgs a, float* __restrict__ dwf, float* __restrict__ dbias, int tiles_x,
+                                                             int tiles_y, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float sx[(LT_H + 2) * (LT_W + 2) * LT_PITCH];
+  float(*red)[8] = reinterpret_cast<float(*)[8]>(sx);  // reused after the last tile: [4 waves * (36 K + K)][8 chunks]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 7, grp = lane >> 3;  // chunk, pixel of the iteration
+  float acc[9][4][K], bacc[K];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[t][e][k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) bacc[k] = 0.f;
+  constexpr int NPIX = (LT_H + 2) * (LT_W + 2), NLD = (NPIX + 31) / 32;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int y0 = ty * LT_H, x0 = tx * LT_W;
+    const float* img = a.x + (int64_t)n * a.H * a.W * a.xcs;
+    float4 stage[NLD];
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int p = (tid >> 3) + 32 * l;
+      const int wy = p / (LT_W + 2), wx = p - wy * (LT_W + 2);
+      int iy = y0 + wy - 1, ix = x0 + wx - 1;
+      if (a.pad_mode) {
+        iy = reflect1(iy, a.H);
+        ix = reflect1(ix, a.W);
+      }
+      const bool ok = p < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      stage[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) stage[l] = *reinterpret_cast<const float4*>(img + ((int64_t)iy * a.W + ix) * a.xcs + 4 * (tid & 7));
+    }
+    __syncthreads();  // the previous tile's reads of sx are done
+#pragma unroll
+    for (int l = 0; l < NLD; ++l) {
+      const int p = (tid >> 3) + 32 * l;
+      if (p < NPIX) *reinterpret_cast<float4*>(sx + p * LT_PITCH + 4 * (tid & 7)) = stage[l];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+      const int ly = 2 * wid + (it >> 2), lx = (it & 3) * 8 + grp;
+      const int oy = y0 + ly, ox = x0 + lx;
+      const bool live = oy < a.H && ox < a.W;
+      struct __attribute__((packed, aligned(4))) GK {
+        float e[K];
+      };
+      GK gk;
+#pragma unroll
+      for (int k = 0; k < K; ++k) gk.e[k] = 0.f;
+      if (live) gk = *reinterpret_cast<const GK*>(a.y + ((int64_t)(n * a.H + oy) * a.W + ox) * a.ycs);
+#pragma unroll
+      for (int k = 0; k < K; ++k) bacc[k] += gk.e[k];
+      const float* base = sx + (ly * (LT_W + 2) + lx) * LT_PITCH + 4 * j;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(base + ((t / 3) * (LT_W + 2) + (t % 3)) * LT_PITCH);
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[t][e][k] = fmaf(xv[e], gk.e[k], acc[t][e][k]);
+      }
+    }
+  }
+  // over the wave's 8 pixel lanes (same chunk j), then the workgroup's waves through LDS, then workgroups by atomics
+  for (int m = 8; m < 64; m <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[t][e][k] += __shfl_xor(acc[t][e][k], m, 64);
+#pragma unroll
+    for (int k = 0; k < K; ++k) bacc[k] += __shfl_xor(bacc[k], m, 64);
+  }
+  __syncthreads();  // sx is free: reuse it for the cross-wave reduction
+  constexpr int NV = 36 * K + K;
+  if (grp == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[wid * NV + (t * 4 + e) * K + k][j] = acc[t][e][k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wid * NV + 36 * K + k][j] = bacc[k];
+  }
+  __syncthreads();
+  for (int i = tid; i < 36 * K * 8; i += 256) {
+    const int v = i >> 3, jj = i & 7;
+    const float s_ = red[v][jj] + red[NV + v][jj] + red[2 * NV + v][jj] + red[3 * NV + v][jj];
+    const int t = v / (4 * K), e = (v / K) & 3, k = v % K;
+    atomicAdd(dwf + ((int64_t)t * a.C + 4 * jj + e) * K + k, s_);
+  }
+  if (dbias && tid < K) {
+    const int v = 36 * K + tid;
+    atomicAdd(dbias + tid, red[v][0] + red[NV + v][0] + red[2 * NV + v][0] + red[3 * NV + v][0]);
+  }
+}
+
 // adjoint with ZERO padding semantics: per-lane quantity = the pixel (B operand = dy of the pixels whose windows cover it), A operand =
 // w[t][4q + r][k]; lane (g, q, i) ends with dx[pixel][4q .. 4q+3] in its accumulator: one 16-byte store.  (Reflect padding: the
 // caller re-computes the two border rows / columns with thin_dgrad_border_kernel, which knows the fold.)
@@ -516,6 +627,15 @@ extern "C" int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x,
   ThinArgs a{x, nullptr, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
+  if (d->C == 32 && !getenv("FMI_THIN_NO_LDS")) {  // halo tile through LDS, persistent workgroups (3 per CU)
+    const int tiles_x = (d->W + LT_W - 1) / LT_W, tiles_y = (d->H + LT_H - 1) / LT_H;
+    const int64_t nt = (int64_t)d->N * tiles_x * tiles_y;
+    if (nt < (1ll << 31)) {
+      const int grid = nt < 768 ? (int)nt : 768;
+      THIN_DISPATCH(thin_wgrad_lds_kernel, a, dwf, dbias, tiles_x, tiles_y, (int)nt);
+      return fmi_launch_status();
+    }
+  }
   const int64_t waves = (total + 64 / G - 1) / (64 / G);
   const int grid = (int)(waves / 4 > 1024 ? 1024 : (waves + 3) / 4);
   THIN_DISPATCH(thin_wgrad_kernel, a, dwf, dbias, G, total);
