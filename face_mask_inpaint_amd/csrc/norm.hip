@@ -6,20 +6,25 @@
 // Layout of a workgroup: 256 threads = PL pixel lanes x CG channel groups (4 channels each), CG = C/4.
 #include "common.h"
 
-#define ROWS_PER_BLOCK 512  // pixels per workgroup chunk
+// pixels per workgroup chunk: 512, grown for large planes so that at most ~2048 workgroups (and fp64 atomics per statistic) exist
+static int rows_per_block(int N, int HW) {
+  int64_t r = 512;
+  while ((int64_t)N * ((HW + r - 1) / r) > 2048 && r < 16384) r *= 2;
+  return (int)r;
+}
 
 // sums[n][c][0..1] += (sum f0, sum f1) where (f0,f1) = fn(x, g) per element
 template <int MODE>  // 0: (x, x*x)   1: backward reductions (g', g'*xhat)
 __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, double* __restrict__ sums, int HW,
-                                                        int C, float slope) {
+                                                        int C, float slope, int rpb) {
   __shared__ float red[256 * 8];
   const int CG = C >> 2, PL = 256 / CG;
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
   const int n = blockIdx.y;
-  const int p0 = blockIdx.x * ROWS_PER_BLOCK;
-  int p1 = p0 + ROWS_PER_BLOCK;
+  const int p0 = blockIdx.x * rpb;
+  int p1 = p0 + rpb;
   if (p1 > HW) p1 = HW;
   float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
   float mean[4] = {0, 0, 0, 0}, rstd[4] = {1, 1, 1, 1}, gm[4] = {1, 1, 1, 1}, bt[4] = {0, 0, 0, 0};
@@ -34,9 +39,8 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
     }
   }
   if (pl < PL) {
-    for (int p = p0 + pl; p < p1; p += PL) {
-      const int64_t o = ((int64_t)n * HW + p) * C + cg * 4;
-      const float4 v = *reinterpret_cast<const float4*>(x + o);
+    // four pixels per iteration: independent 16-byte loads in flight (a single dependent load per thread reached 1.4 TB/s)
+    auto body = [&](const float4 v, const float4 g4) {
       const float xv[4] = {v.x, v.y, v.z, v.w};
       if (MODE == 0) {
 #pragma unroll
@@ -45,7 +49,6 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
           a1[e] += xv[e] * xv[e];
         }
       } else {
-        const float4 g4 = *reinterpret_cast<const float4*>(gy + o);
         const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -56,6 +59,22 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
           a1[e] += gp * xh;
         }
       }
+    };
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+      float4 v[4], g4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t o = ((int64_t)n * HW + p + u * PL) * C + cg * 4;
+        v[u] = *reinterpret_cast<const float4*>(x + o);
+        g4[u] = MODE == 1 ? *reinterpret_cast<const float4*>(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(v[u], g4[u]);
+    }
+    for (; p < p1; p += PL) {
+      const int64_t o = ((int64_t)n * HW + p) * C + cg * 4;
+      body(*reinterpret_cast<const float4*>(x + o), MODE == 1 ? *reinterpret_cast<const float4*>(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
 #pragma unroll
@@ -103,9 +122,10 @@ extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats
   if (!x || !sums || !stats || N <= 0 || HW <= 0 || C <= 0 || ((uintptr_t)x & 15)) return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((HW + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, N);
+  const int rpb = rows_per_block(N, HW);
+  dim3 grid((HW + rpb - 1) / rpb, N);
   hipLaunchKernelGGL((in_reduce_kernel<0>), grid, dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, sums, HW, C, 1.f);
+                     (const float*)nullptr, (const float*)nullptr, sums, HW, C, 1.f, rpb);
   hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const double*)sums, stats, N * C, HW, eps);
   return fmi_launch_status();
 }
@@ -144,8 +164,9 @@ extern "C" int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, cons
   if (!x || !gy || !stats || !gamma || !beta || !red || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)gy & 15))
     return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
-  dim3 grid((HW + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, N);
-  hipLaunchKernelGGL((in_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, stats, gamma, beta, red, HW, C, slope);
+  const int rpb = rows_per_block(N, HW);
+  dim3 grid((HW + rpb - 1) / rpb, N);
+  hipLaunchKernelGGL((in_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, stats, gamma, beta, red, HW, C, slope, rpb);
   return fmi_launch_status();
 }
 
