@@ -80,6 +80,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   ConvWX lb{wf, g, w_bstride, d->K, (d->K % 4 == 0) && aligned16(wf) && (w_bstride % 4 == 0)};
   ConvEp ep{y, bias, residual, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, act, g.dGW, g.dG,
             (int64_t)d->OH * d->OW * d->y_cstride};
+  ep.vec = !getenv("FMI_EP_SCALAR") && d->K % 4 == 0 && d->y_cstride % 4 == 0 && aligned16(y) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
   const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
   static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
@@ -94,6 +95,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
       ep.bias = nullptr;
       ep.res = nullptr;
       ep.act = 3;
+      ep.vec = 0;
     }
     return launch_conv3x3(ca, ep, g.Mdim(), ks, (hipStream_t)stream);
   }
@@ -104,6 +106,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
     ep.bias = nullptr;
     ep.res = nullptr;
     ep.act = 3;
+    ep.vec = 0;
     return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), 1, ks, (hipStream_t)stream);
   }
 #endif
@@ -145,6 +148,7 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
       ConvWX lb{wt, g, w_bstride, d->C, (d->C % 4 == 0) && aligned16(wt) && (w_bstride % 4 == 0)};
       ConvEp ep{dx, bias, residual, GH, GW, s, py, px, d->H, d->W, d->x_cstride, 0, g.dGW, g.dG,
                 (int64_t)d->H * d->W * d->x_cstride};
+      ep.vec = !getenv("FMI_EP_SCALAR") && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
       const int ks = (s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1;
       static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
@@ -159,6 +163,7 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
           ep.bias = nullptr;
           ep.res = nullptr;
           ep.act = 3;
+          ep.vec = 0;
         }
         rc = launch_conv3x3(ca, ep, g.Mdim(), ks, (hipStream_t)stream);
         if (rc) return rc;
@@ -171,6 +176,7 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
         ep.bias = nullptr;
         ep.res = nullptr;
         ep.act = 3;
+        ep.vec = 0;
         rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, ks, (hipStream_t)stream);
         if (rc) return rc;
         continue;

@@ -374,6 +374,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
 // Epilogues: row_off(row) -> element offset of the row, then store(off, col, acc).
 // =====================================================================================
 struct DenseEp {
+  static constexpr bool HAS_VEC4 = false;
   float* c;
   const float* bias;
   int64_t sc_m, sc_n, bs;
@@ -401,9 +402,24 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
   int GH, GW, OS, py, px, OHt, OWt, cstride, act;
   FastDiv dGW, dG;
   int64_t bs;
+  int vec = 0;  // 16-byte epilogue allowed: N % 4 == 0, cstride % 4 == 0, y / res / bias 16-byte aligned, not the atomic mode
+  static constexpr bool HAS_VEC4 = true;
   __device__ void set_batch(int b) {
     y += (int64_t)b * bs;
     if (res) res += (int64_t)b * bs;
+  }
+  __device__ void store4(int64_t off, int col, float4 v) const {  // columns col .. col+3 of one row
+    if (bias) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+      v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+    }
+    if (res) {
+      const float4 r4 = *reinterpret_cast<const float4*>(res + off + col);
+      v.x += r4.x, v.y += r4.y, v.z += r4.z, v.w += r4.w;
+    }
+    if (act == 1) v.x = tanhf(v.x), v.y = tanhf(v.y), v.z = tanhf(v.z), v.w = tanhf(v.w);
+    else if (act == 2) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+    *reinterpret_cast<float4*>(y + off + col) = v;
   }
   __device__ int64_t row_off(int row) const {
     const uint32_t n = fdiv((uint32_t)row, dG);
@@ -426,6 +442,7 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
 };
 
 struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 atomics across the split reduction
+  static constexpr bool HAS_VEC4 = false;
   float* dw;
   ConvGeom g;
   int Kout;
@@ -448,8 +465,56 @@ struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 at
 
 #ifndef FMI_HOST_EMU
 // epilogue shared by the kernels: register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31 of its 32x32 tile
+// 4 x 4 transpose inside every quad of lanes (DPP quad_perm): register rho of lane c  <->  register c of lane rho
+__device__ __forceinline__ float dpp_quad(float v, bool stage2) {
+  const int i = __float_as_int(v);
+  return __int_as_float(stage2 ? __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true)    // quad_perm [2,3,0,1]
+                               : __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int c) {
+  const bool b0 = c & 1, b1 = c & 2;
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {
+    const float recv = dpp_quad(b0 ? a[p] : a[p + 1], false);
+    a[p] = b0 ? recv : a[p];
+    a[p + 1] = b0 ? a[p + 1] : recv;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float recv = dpp_quad(b1 ? a[q] : a[q + 2], true);
+    a[q] = b1 ? recv : a[q];
+    a[q + 2] = b1 ? a[q + 2] : recv;
+  }
+}
+
 template <class EP, class T>
 __device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T::TN], int M, int N, int row0, int col0, int lh, int l31) {
+  if constexpr (EP::HAS_VEC4) {
+    if (ep.vec) {
+      // The accumulator layout gives a lane ONE column and 16 rows: 64 four-byte stores per 32 x 32 tile and lane, each wave
+      // instruction two 128-byte row pieces.  The texture path is paced per wave instruction, so tiles with a short reduction
+      // (ConvTranspose phases, 1x1 convolutions) were bound by their epilogue.  A 4 x 4 transpose inside each quad of lanes turns
+      // registers 4g .. 4g+3 (rows 8g + 4 lh + 0..3, column l) into ONE row and four consecutive columns per lane: 16-byte stores
+      // (and residual / bias loads), four times fewer instructions.
+      const int c = l31 & 3, colq = l31 & ~3;
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + i * 32 + 8 * g + 4 * lh + c;
+          const int64_t off = row < M ? ep.row_off(row) : 0;
+#pragma unroll
+          for (int j = 0; j < T::TN; ++j) {
+            float a[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            quad_transpose(a, c);
+            const int col = col0 + j * 32 + colq;
+            if (row < M && col < N) ep.store4(off, col, make_float4(a[0], a[1], a[2], a[3]));
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
