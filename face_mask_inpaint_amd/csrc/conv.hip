@@ -56,7 +56,12 @@ static int conv_ksplit(int64_t M, int N, int K) {
 #else
   // keep the 128-wide tiles (operand reuse) and fill the chip by splitting the reduction instead of shrinking the tile
   const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128));
-  if (tiles >= 320 || K < 512) return 1;
+  if (K < 512) return 1;
+  if (tiles >= 320) {
+    // between one and two "waves" of workgroups (3 per CU x 256 CUs) the CUs that got 3 tiles set the time while the others idle
+    // (VGG 28^2: 588 tiles = 2.3 per CU): halving the work unit lets the dispatcher even it out
+    return tiles < 1200 && K >= 2304 ? 3 : 1;
+  }
   int64_t ks = ceil_div64(384, tiles);
   if (ks > K / 256) ks = K / 256;  // at least 16 k-tiles per split
   return ks < 2 ? 1 : (int)(ks > 16 ? 16 : ks);

@@ -186,7 +186,9 @@ static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, 
     if (M > 64 && wgs(128, 64) >= 384) C3_LAUNCH(Tile128x64);
     else C3_LAUNCH(Tile64x64);
   } else {
-    if (M > 64 && wgs(128, 128) >= 384) C3_LAUNCH(Tile128x128);
+    // between one and two rounds of 128x128 workgroups (3 per CU) the fullest CUs set the time: halve the work unit instead
+    // (VGG 28^2: 588 tiles = 2.3 per CU, 94 -> 100 TFLOP/s with 64x128; at 1176 tiles the 128x128 tile wins again, 114 vs 102)
+    if (M > 64 && wgs(128, 128) >= 800) C3_LAUNCH(Tile128x128);
     else C3_LAUNCH(Tile64x128);
   }
 #undef C3_LAUNCH
