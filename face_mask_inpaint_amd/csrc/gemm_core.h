@@ -973,14 +973,15 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
   // largest tile that still gives ~1.5 workgroups per CU; small problems trade operand reuse for occupancy
   const int64_t zs = gy;
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn) * zs; };
-  const int64_t want = 384;
+  const int64_t want = 384, want128 = 800;  // 128x128 only from ~one full round of workgroups (3 per CU) up: below that the
+                                           // fullest CUs set the time and the 64x128 tile balances better (measured: -0.7 ms per step)
   if (N <= 32) {
     FMI_LAUNCH(Tile128x32);
   } else if (N <= 64) {
     if (M > 64 && wgs(128, 64) >= want) FMI_LAUNCH(Tile128x64);
     else FMI_LAUNCH(Tile64x64);
   } else {
-    if (M > 64 && wgs(128, 128) >= want) FMI_LAUNCH(Tile128x128);
+    if (M > 64 && wgs(128, 128) >= want128) FMI_LAUNCH(Tile128x128);
     else if (M > 32 && wgs(64, 128) >= want) FMI_LAUNCH(Tile64x128);
     else if (M > 64 && wgs(32, 128) < 256) FMI_LAUNCH(Tile64x128);
     else FMI_LAUNCH(Tile32x128);
