@@ -107,6 +107,8 @@ struct DenseK {  // reduction index contiguous in memory
   __device__ DCtx dprep(int x, int kq) const { return DCtx{(int64_t)x * ld + kq, x < X ? kq : 0x40000000}; }
   __device__ Tile tile(int k0) const { return Tile{p + k0, K - k0}; }
   __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kq < t.krem ? t.base + d.off : nullptr; }
+  __device__ void dstart(DCtx&, int) const {}
+  __device__ void advance(DCtx&) const {}
 };
 
 struct DenseX {  // row/column index contiguous in memory
@@ -140,6 +142,8 @@ struct DenseX {  // row/column index contiguous in memory
   __device__ DCtx dprep(int x, int kr) const { return DCtx{(int64_t)kr * ld + x, x < X ? kr : 0x40000000}; }
   __device__ Tile tile(int k0) const { return Tile{p + (int64_t)k0 * ld, K - k0}; }
   __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kr < t.krem ? t.base + d.off : nullptr; }
+  __device__ void dstart(DCtx&, int) const {}
+  __device__ void advance(DCtx&) const {}
 };
 
 // Geometry of one implicit-GEMM launch.  Rows enumerate a grid [N][GH][GW] of "anchor" positions;
@@ -246,6 +250,8 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     const bool ok = (unsigned)(d.ry + t.dy) < (unsigned)g.IH && (unsigned)(d.rx + t.dx) < (unsigned)g.IW;
     return ok ? p + d.boff + t.uoff : nullptr;
   }
+  __device__ void dstart(DCtx&, int) const {}
+  __device__ void advance(DCtx&) const {}
 };
 
 struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [tap][Cred][Nout]
@@ -291,6 +297,8 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
     return Tile{ok ? q : nullptr};
   }
   __device__ const float* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? t.base + d.off : nullptr; }
+  __device__ void dstart(DCtx&, int) const {}
+  __device__ void advance(DCtx&) const {}
 };
 
 struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), reduction = anchors
@@ -352,10 +360,31 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
   struct DCtx {
     Ctx c;
     int x, kr, dy, dx;
+    int k, n, gy, gx;  // anchor (reduction index) this slot fetches in the NEXT tile: walked incrementally, 16 anchors per tile
   };
   struct Tile {
     int k0;
   };
+  __device__ void dstart(DCtx& d, int k_begin) const {
+    d.k = k_begin + d.kr;
+    const uint32_t n = fdiv((uint32_t)d.k, g.dG);
+    const uint32_t rem = (uint32_t)d.k - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    d.n = (int)n;
+    d.gy = (int)gy;
+    d.gx = (int)(rem - gy * (uint32_t)g.GW);
+  }
+  __device__ void advance(DCtx& d) const {
+    d.k += 16;
+    d.gx += 16;
+    while (d.gx >= g.GW) {
+      d.gx -= g.GW;
+      if (++d.gy == g.GH) {
+        d.gy = 0;
+        ++d.n;
+      }
+    }
+  }
   __device__ DCtx dprep(int x, int kr) const {
     DCtx d;
     d.c = prep(x);
@@ -535,22 +564,18 @@ __device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T:
 static __device__ __attribute__((aligned(16))) float fmi_chunk_zero[4] = {0.f, 0.f, 0.f, 0.f};
 static __device__ __attribute__((aligned(16))) float fmi_chunk_one[4] = {1.f, 0.f, 0.f, 0.f};
 
-__device__ inline const float* WgradAX::chunk(const DCtx& d, const Tile& t) const {
-  const int k = t.k0 + d.kr;
-  if (k >= g.Mdim()) return nullptr;
+__device__ inline const float* WgradAX::chunk(const DCtx& d, const Tile&) const {
+  if (d.k >= g.Mdim()) return nullptr;
   if (d.x == ones_row) return fmi_chunk_one;
   if (d.c.t0 >= g.ntaps()) return nullptr;
-  const uint32_t n = fdiv((uint32_t)k, g.dG);
-  const uint32_t rem = (uint32_t)k - n * (uint32_t)(g.GH * g.GW);
-  const uint32_t gy = fdiv(rem, g.dGW);
-  const uint32_t gx = rem - gy * (uint32_t)g.GW;
-  int iy = (int)gy * g.S + d.dy, ix = (int)gx * g.S + d.dx;
+  const int n = d.n;
+  int iy = d.gy * g.S + d.dy, ix = d.gx * g.S + d.dx;
   if (g.pad_mode) {
     iy = reflect_idx(iy, g.IH);
     ix = reflect_idx(ix, g.IW);
   }
   if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return nullptr;
-  return p + ((int64_t)((int)n * g.IH + iy) * g.IW + ix) * g.cstride + d.c.c0;
+  return p + ((int64_t)(n * g.IH + iy) * g.IW + ix) * g.cstride + d.c.c0;
 }
 #endif
 
@@ -791,6 +816,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
       x = (p % (BM / 4)) * 4;
     }
     da[j] = la.dprep(m0 + x, k);
+    la.dstart(da[j], k_begin);
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
@@ -804,6 +830,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
       x = (p % (BN / 4)) * 4;
     }
     db[j] = lb.dprep(n0 + x, k);
+    lb.dstart(db[j], k_begin);
   }
   // wave-uniform: does copy slot j of this wave exist (tiles narrower than 64 rows fill only waves 0..1)
   const int na_w = (BM % 64 == 0) ? NLA : (wid * 64 < BM * 4 ? 1 : 0);
@@ -839,6 +866,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
       const float* g = la.chunk(da[j], ta);
       if (!g) g = fmi_chunk_zero;
       glds16(g, sa + j * 4096);
+      la.advance(da[j]);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
@@ -846,6 +874,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
       const float* g = lb.chunk(db[j], tb);
       if (!g) g = fmi_chunk_zero;
       glds16(g, sb + j * 4096);
+      lb.advance(db[j]);
     }
   };
   auto compute = [&](int st) {
