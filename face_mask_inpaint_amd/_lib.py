@@ -43,6 +43,7 @@ SIGNATURES = {
     "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, vp, i32, i64, vp],
     "fmi_conv2d_thin_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, vp],
     "fmi_conv2d_thin_dgrad_f32": [PD, vp, vp, vp, vp],
+    "fmi_conv2d_thin_input_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_wgrad_f32": [PD, vp, vp, vp, vp, vp],
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],

@@ -128,6 +128,10 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
 #ifndef FMI_HOST_EMU
   if (batch_w == 1 && !bias && !residual && fmi_conv2d_thin_supported(d) && aligned16(dx))
     return fmi_conv2d_thin_dgrad_f32(d, dy, wt, dx, stream);
+  if (batch_w == 1 && !bias && !residual && d->C <= 4 && d->x_cstride == d->C) {  // thin INPUT: VGG16's first layer
+    const int rc_thin = fmi_conv2d_thin_input_dgrad_f32(d, dy, wt, dx, stream);
+    if (rc_thin != FMI_ERR_UNSUPPORTED) return rc_thin;
+  }
 #endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;

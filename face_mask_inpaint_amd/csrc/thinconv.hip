@@ -30,6 +30,7 @@ struct ThinArgs {
   const float* res;  // y layout
   float* y;          // [N,H,W,K] pixel pitch ycs
   int N, H, W, C, K, xcs, ycs, pad_mode, act;
+  int flip = 0;  // weights indexed with tap 8 - t: the adjoint of a THIN-INPUT convolution (C_in <= 4) is a thin-output convolution of dy
 };
 
 template <int K>
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256) thin_fwd_mfma_kernel(ThinArgs a, int qbit
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)t * a.C + 4 * q + e) * K + i] : 0.f;
+    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)(a.flip ? 8 - t : t) * a.C + 4 * q + e) * K + i] : 0.f;
   const int wave = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int)(((int64_t)gridDim.x * 256) >> 6);
   for (int task = wave; task < ntasks; task += nwaves) {
     const RowTask rt = row_task(__builtin_amdgcn_readfirstlane(task), a.H, segs);
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256) thin_fwd_lds_kernel(ThinArgs a, int tiles
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)t * a.C + 4 * q + e) * K + i] : 0.f;
+    for (int e = 0; e < 4; ++e) wr[t][e] = i < K ? a.w[((int64_t)(a.flip ? 8 - t : t) * a.C + 4 * q + e) * K + i] : 0.f;
   // stage the window: chunk c8 = tid & 7 of window pixel (tid >> 3) + 32 j
   const float* img = a.x + (int64_t)n * a.H * a.W * a.xcs;
   constexpr int NPIX = (LT_H + 2) * (LT_W + 2), NLD = (NPIX + 31) / 32;
@@ -614,6 +615,31 @@ extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy
     const int64_t nb = (int64_t)d->N * (2 * d->W + 2 * d->H) * (d->C / 4);
     const int grid = (int)((nb + 255) / 256);
     THIN_DISPATCH(thin_dgrad_border_kernel, a, dx, nb);
+  }
+  return fmi_launch_status();
+}
+
+/* Adjoint of a THIN-INPUT convolution (C_in <= 4, e.g. VGG16's first layer 3 -> 64, whose input gradient d loss / d image the
+ * generator needs): dx[N,H,W,C<=4] = thin-output convolution of dy[N,H,W,K] with wt[tap][K][C] and flipped taps (zero padding). */
+extern "C" int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream) {
+  if (!d || !dy || !wt || !dx) return FMI_ERR_BAD_ARG;
+  const int cg = d->K / 4;
+  if (d->C < 1 || d->C > 4 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->K % 4 != 0 || cg < 1 ||
+      cg > 16 || (cg & (cg - 1)) != 0 || d->y_cstride % 4 != 0 || d->H < 3 || d->W < 3 || d->OH != d->H || d->OW != d->W ||
+      ((uintptr_t)dy & 15) || (int64_t)d->N * d->H * d->W >= (1ll << 31))
+    return FMI_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  ThinArgs a{dy, wt, nullptr, nullptr, dx, d->N, d->H, d->W, d->K, d->C, d->y_cstride, d->x_cstride, 0, 0};
+  a.flip = 1;
+  int qbits = 0;
+  while ((1 << qbits) < cg) ++qbits;
+  const int segs = (d->W + SEG - 1) / SEG, ntasks = d->N * d->H * segs;
+  const int grid = ntasks / 4 > 8192 ? 8192 : (ntasks + 3) / 4;
+  switch (d->C) {
+    case 1: hipLaunchKernelGGL((thin_fwd_mfma_kernel<1>), dim3(grid), dim3(256), 0, st, a, qbits, ntasks, segs); break;
+    case 2: hipLaunchKernelGGL((thin_fwd_mfma_kernel<2>), dim3(grid), dim3(256), 0, st, a, qbits, ntasks, segs); break;
+    case 3: hipLaunchKernelGGL((thin_fwd_mfma_kernel<3>), dim3(grid), dim3(256), 0, st, a, qbits, ntasks, segs); break;
+    default: hipLaunchKernelGGL((thin_fwd_mfma_kernel<4>), dim3(grid), dim3(256), 0, st, a, qbits, ntasks, segs); break;
   }
   return fmi_launch_status();
 }

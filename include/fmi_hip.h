@@ -101,6 +101,9 @@ int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float*
                             const float* residual, float* y, int act, void* stream);
 int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);
 int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias, void* stream);
+/* adjoint of a thin-INPUT 3x3 convolution (C <= 4, K = 4..64 a power of two, stride 1, pad 1, zeros): dx = thin-output convolution of
+ * dy with flipped taps -- the input gradient of VGG16's first layer (loss.py:45-65); fmi_conv2d_dgrad_f32 routes to it by itself */
+int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);
 /* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
 int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);
 /* fold the gradient w.r.t. a reflection-padded tensor [N,H+2p,W+2p,C] back onto [N,H,W,C]. */

@@ -522,6 +522,28 @@ def test_thin_output_conv(dev, FF, n, c, k, h, w, pad_mode, act):
         torch.testing.assert_close(dx2.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c,k,h,w", [(2, 3, 64, 40, 36), (1, 3, 32, 130, 200), (2, 1, 16, 9, 7), (1, 4, 8, 3, 3), (2, 2, 4, 17, 5)])
+def test_thin_input_conv_adjoint(dev, FF, n, c, k, h, w):
+    """input gradient of a thin-INPUT 3x3 convolution (VGG16's first layer 3 -> 64, loss.py:45-65): the dedicated entry and the
+    generic dgrad entry that routes to it, against autograd"""
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(h * 7 + c + k)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt_ = torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5
+    gy = torch.randn(n, k, h, w, generator=g)
+    F.conv2d(x, wt_, padding=1).backward(gy)
+    d, _, _ = FF.conv_desc(n, h, w, c, k, 3, 3, 1, 1, 0)
+    wtp = pack(wt_)[1].to(dev)
+    gh, st = nhwc(gy).to(dev), FF._st()
+    for fn in (lambda dx: lib.conv2d_thin_input_dgrad_f32(C.byref(d), FF._p(gh), FF._p(wtp), FF._p(dx), st),
+               lambda dx: lib.conv2d_dgrad_f32(C.byref(d), FF._p(gh), FF._p(wtp), None, None, FF._p(dx), 1, 0, st)):
+        dx = torch.full((n, h, w, c), float("nan"), device=dev)
+        fn(dx)
+        torch.testing.assert_close(dx.cpu(), nhwc(x.grad), rtol=1e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("n,h,c", [(3, 16, 64), (2, 64, 128), (16, 32, 512), (2, 8, 256), (2, 16, 12)])
 def test_global_average_pool(dev, FF, n, h, c):
     """AdaptiveAvgPool2d(1) of the SE modules (helpers.py:56-72): reduction path (and the windowed fallback for C = 12)"""
