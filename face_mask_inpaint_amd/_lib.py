@@ -45,6 +45,17 @@ SIGNATURES = {
     "fmi_conv2d_thin_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_input_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_wgrad_f32": [PD, vp, vp, vp, vp, vp],
+    "fmi_conv2d_fwd_bf16": [PD, vp, vp, vp, vp, vp],
+    "fmi_conv2d_dgrad_bf16": [PD, vp, vp, vp, vp, vp],
+    "fmi_conv2d_wgrad_bf16": [PD, vp, vp, vp, vp],
+    "fmi_pack_weight_bf16": [vp, vp, i32, i32, i32, vp],
+    "fmi_scale_channels_bf16": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_scale_channels_gs_bf16": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_noise_bias_act_bf16": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
+    "fmi_noise_bias_act_bwd_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
+    "fmi_upfirdn2d_nhwc_bf16": [vp, vp, vp] + [i32] * 14 + [vp],
+    "fmi_torgb_fwd_bf16": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
+    "fmi_torgb_bwd_bf16": [vp] * 9 + [i32, i64, i32, vp],
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_weight_prepare_f32": [vp, i32, vp],
@@ -103,7 +114,7 @@ SIGNATURES = {
 STATUS = {0: "ok", 1: "bad argument", 2: "unsupported shape/mode", 3: "kernel launch failed"}
 
 
-PREDICATES = {"fmi_conv2d_thin_supported": [PD]}
+PREDICATES = {"fmi_conv2d_thin_supported": [PD], "fmi_conv2d_bf16_supported": [PD]}
 
 
 class FmiError(RuntimeError):

@@ -1,0 +1,574 @@
+// bf16 implicit-GEMM convolution family for the StyleGAN2 decoder of the pSp path (stylegan2/model.py:241-279, configs C3 / C5:
+// bf16 compute, fp32 accumulate): forward, adjoint (= ConvTranspose2d forward / input gradient) and weight gradient.
+//
+// Machine mapping (gfx950):
+//  * v_mfma_f32_32x32x16_bf16: lane l supplies A[row l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][col l&31] as eight bf16
+//    (one 16-byte register quad); the 32x32 fp32 result has the layout of the fp32 core (gemm_core.h).
+//  * operands reach LDS by global_load_lds_dwordx4 (LDS-DMA), 16 bytes = 8 bf16 per lane, two-stage ring, one raw s_barrier and a
+//    counted s_waitcnt vmcnt per reduction tile -- the pipeline of gemm_dma_f32_kernel.
+//  * forward / adjoint: both operands have the reduction index contiguous in memory (NHWC pixels x (tap, channel); weights packed
+//    [out][tap][in]), so a tile image is [row][BK bf16] and ONE ds_read_b128 is one MFMA operand.  BK = 64 (128-byte rows, whole
+//    cache lines per row) when the channel count allows, else 32.  The 16-byte chunk index is XOR-swizzled on the SOURCE address
+//    (the DMA writes lane-linear) and on the read: (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows -- every 16-lane
+//    group of a ds_read_b128 then covers all 64 banks once.
+//  * weight gradient: the reduction runs over pixels, which are the SLOW index of both x[pixel][c] and dy[pixel][k]; the MFMA
+//    operands come from ds_read_b64_tr_b16 (hardware transpose of a 4-pixel x 16-row block per 16 lanes), two per operand.  The
+//    image is [32-row group][64 pixels][32 rows]: the four pixel rows one transposed read touches are 256 contiguous bytes (one
+//    bank row, conflict-free without a swizzle) and all copies of a thread belong to one pixel (one anchor decode per tile).
+#include "gemm_core.h"
+
+#ifndef FMI_HOST_EMU
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even (inputs are finite)
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+static bool aligned16b(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// loaders (LDS-DMA hooks only: chunk = 8 consecutive reduction elements of one row)
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ConvKB {  // A operand: gathered pixels x (tap, channel); a reduction tile lies inside one tap (C % BK == 0), zero padding
+  const bf16_t* p;
+  ConvGeom g;
+  struct DCtx {
+    int64_t boff;
+    int ry, rx;
+  };
+  struct Tile {
+    int dy, dx;
+    int64_t uoff;
+  };
+  __device__ DCtx dprep(int x, int kq) const {
+    DCtx d;
+    if (x >= g.Mdim()) {
+      d.ry = -0x20000000, d.rx = 0, d.boff = 0;
+      return d;
+    }
+    const uint32_t n = fdiv((uint32_t)x, g.dG);
+    const uint32_t rem = (uint32_t)x - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    d.ry = (int)gy * g.S + g.dy0;
+    d.rx = (int)gx * g.S + g.dx0;
+    d.boff = ((int64_t)((int)n * g.IH + d.ry) * g.IW + d.rx) * g.cstride + kq;
+    return d;
+  }
+  __device__ Tile tile(int k0) const {
+    const int tp = (int)fdiv((uint32_t)k0, g.dC);
+    const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
+    Tile t;
+    t.dy = tp < g.ntaps() ? g.ystep * i : -0x20000000;
+    t.dx = g.xstep * j;
+    t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * g.cstride + (k0 - tp * g.C);
+    return t;
+  }
+  __device__ const bf16_t* chunk(const DCtx& d, const Tile& t) const {
+    const bool ok = (unsigned)(d.ry + t.dy) < (unsigned)g.IH && (unsigned)(d.rx + t.dx) < (unsigned)g.IW;
+    return ok ? p + d.boff + t.uoff : nullptr;
+  }
+};
+
+struct ConvWKB {  // B operand: weights packed [Nout][T taps][Cred] (reduction contiguous)
+  const bf16_t* p;
+  ConvGeom g;  // tap algebra and C
+  int Nout, T;
+  struct DCtx {
+    int64_t off;
+  };
+  struct Tile {
+    int toff;
+  };
+  __device__ DCtx dprep(int x, int kq) const { return DCtx{x < Nout ? (int64_t)x * T * g.C + kq : -1}; }
+  __device__ Tile tile(int k0) const {
+    const int tp = (int)fdiv((uint32_t)k0, g.dC);
+    if (tp >= g.ntaps()) return Tile{-1};
+    const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    return Tile{wtap * g.C + (k0 - tp * g.C)};
+  }
+  __device__ const bf16_t* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.toff >= 0) ? p + d.off + t.toff : nullptr; }
+};
+
+struct ConvEpB {  // rows = anchors, written at (gy*OS+py, gx*OS+px) of the bf16 tensor [N][OHt][OWt][cstride]
+  bf16_t* y;
+  const float* colscale;  // [N][Nout] or null: y *= colscale[sample][col] (demodulation, model.py:250-252)
+  int GH, GW, OS, py, px, OHt, OWt, cstride, Nout;
+  FastDiv dGW, dG;
+  int vec;
+  __device__ int64_t row_off(int row, int& n_out) const {
+    const uint32_t n = fdiv((uint32_t)row, dG);
+    const uint32_t rem = (uint32_t)row - n * (uint32_t)(GH * GW);
+    const uint32_t gy = fdiv(rem, dGW);
+    const uint32_t gx = rem - gy * (uint32_t)GW;
+    n_out = (int)n;
+    return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward / adjoint kernel
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class T, int BK>
+__global__ void __launch_bounds__(256) conv_bf16_kernel(ConvKB la, ConvWKB lb, ConvEpB ep, int M, int N, int K, int tiles_n) {
+  constexpr int BM = T::BM, BN = T::BN;
+  constexpr int CPR = BK / 8;            // 16-byte chunks per image row
+  constexpr int RPI = 64 / CPR;          // image rows one wave instruction (1 KiB) fills
+  constexpr int NLA = (BM * CPR + 255) / 256, NLB = (BN * CPR + 255) / 256;
+  constexpr int STAGE = (BM + BN) * BK;  // bf16 elements
+  constexpr int NST = 2;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NST * STAGE];
+  (void)RPI;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+
+  auto swz = [](int row) { return CPR == 8 ? (row >> 1) & 7 : (row >> 2) & 3; };
+
+  ConvKB::DCtx da[NLA];
+  ConvWKB::DCtx db[NLB];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int p = j * 256 + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
+    da[j] = la.dprep(m0 + x, c * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int p = j * 256 + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
+    db[j] = lb.dprep(n0 + x, c * 8);
+  }
+  // images smaller than 256 chunks are filled by the first waves only (wave-uniform)
+  const int na_w = (BM * CPR % 256 == 0) ? NLA : (wid * 64 < BM * CPR ? 1 : 0);
+  const int nb_w = (BN * CPR % 256 == 0) ? NLB : (wid * 64 < BN * CPR ? 1 : 0);
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)lds;
+  auto glds16 = [&](const void* g, uint32_t dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+  };
+  auto issue = [&](int k0, int st) {
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE) * 2u + (uint32_t)wid * 1024u);
+    const uint32_t sb = sa + BM * BK * 2;
+    const ConvKB::Tile ta = la.tile(k0);
+    const ConvWKB::Tile tb = lb.tile(k0);
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      if (BM * CPR % 256 != 0 && !na_w) break;
+      const void* g = la.chunk(da[j], ta);
+      if (!g) g = fmi_chunk_zero;
+      glds16(g, sa + j * 4096);
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      if (BN * CPR % 256 != 0 && !nb_w) break;
+      const void* g = lb.chunk(db[j], tb);
+      if (!g) g = fmi_chunk_zero;
+      glds16(g, sb + j * 4096);
+    }
+  };
+  auto compute = [&](int st) {
+    const bf16_t* sa = lds + st * STAGE;
+    const bf16_t* sb = sa + BM * BK;
+    bf16x8 fa[T::TM][BK / 16], fb[T::TN][BK / 16];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const int r = wm + i * 32 + l31, sw = swz(r);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) fa[i][s] = *reinterpret_cast<const bf16x8*>(sa + r * BK + (((2 * s + lh) ^ sw) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+      const int r = wn + j * 32 + l31, sw = swz(r);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) fb[j][s] = *reinterpret_cast<const bf16x8*>(sb + r * BK + (((2 * s + lh) ^ sw) << 3));
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s)
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+  };
+  auto wait_copies = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+  };
+  const int nt = (K + BK - 1) / BK;
+  const int nw = (BM * CPR % 256 == 0 && BN * CPR % 256 == 0) ? NLA + NLB : na_w + nb_w;
+  if (nt > 0) issue(0, 0);
+  int st = 0;
+  for (int t = 0; t < nt; ++t) {
+    wait_copies(0);  // with a two-stage ring only tile t is in flight here
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) issue((t + 1) * BK, st ^ 1);
+    compute(st);
+    st ^= 1;
+  }
+  (void)nw;
+
+  // epilogue: 4 x 4 transpose inside each quad of lanes -> one row, four consecutive columns per lane, 8-byte bf16 stores
+  const int c = l31 & 3, colq = l31 & ~3;
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = m0 + wm + i * 32 + 8 * g + 4 * lh + c;
+      int n_s = 0;
+      const int64_t off = row < M ? ep.row_off(row, n_s) : 0;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        float a[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        quad_transpose(a, c);
+        const int col = n0 + wn + j * 32 + colq;
+        if (row >= M || col >= N) continue;
+        if (ep.colscale) {
+          const float* cs = ep.colscale + (int64_t)n_s * ep.Nout + col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) a[e] *= cs[e];
+        }
+        if (ep.vec) {
+          uint2 v;
+          v.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+          v.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+          *reinterpret_cast<uint2*>(ep.y + off + col) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) ep.y[off + col + e] = f2bf(a[e]);
+        }
+      }
+    }
+  }
+}
+
+template <int BK>
+static int launch_conv_bf16(const ConvKB& la, const ConvWKB& lb, const ConvEpB& ep, int M, int N, int K, hipStream_t st) {
+#define FMI_LAUNCH_B(TILE)                                                                                                        \
+  do {                                                                                                                            \
+    const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                                     \
+    if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                       \
+    hipLaunchKernelGGL((conv_bf16_kernel<TILE, BK>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn); \
+  } while (0)
+  auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn); };
+  if (N <= 32) {
+    FMI_LAUNCH_B(Tile128x32);
+  } else if (N <= 64) {
+    if (wgs(128, 64) >= 384) FMI_LAUNCH_B(Tile128x64);
+    else FMI_LAUNCH_B(Tile64x64);
+  } else {
+    if (wgs(128, 128) >= 512) FMI_LAUNCH_B(Tile128x128);
+    else if (wgs(64, 128) >= 256) FMI_LAUNCH_B(Tile64x128);
+    else FMI_LAUNCH_B(Tile64x64);
+  }
+#undef FMI_LAUNCH_B
+  return fmi_launch_status();
+}
+
+static int check_desc_b(const fmi_conv_desc* d) {
+  if (!d) return FMI_ERR_BAD_ARG;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0 ||
+      d->x_cstride < d->C || d->y_cstride < d->K)
+    return FMI_ERR_BAD_ARG;
+  if (d->OH != (d->H + 2 * d->pad - d->kh) / d->stride + 1 || d->OW != (d->W + 2 * d->pad - d->kw) / d->stride + 1) return FMI_ERR_BAD_ARG;
+  if (d->OH <= 0 || d->OW <= 0) return FMI_ERR_BAD_ARG;
+  if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;
+  if ((int64_t)d->N * d->H * d->W > 0x7fffffffLL / 2 || (int64_t)d->N * d->OH * d->OW > 0x7fffffffLL / 2 ||
+      (int64_t)d->kh * d->kw * d->C > 0x3fffffffLL || (int64_t)d->kh * d->kw * d->K > 0x3fffffffLL)
+    return FMI_ERR_UNSUPPORTED;
+  return FMI_OK;
+}
+
+extern "C" int fmi_conv2d_bf16_supported(const fmi_conv_desc* d) {
+  if (check_desc_b(d) != FMI_OK) return 0;
+  return d->C % 32 == 0 && d->K % 32 == 0 && d->x_cstride % 8 == 0 && d->y_cstride % 8 == 0;
+}
+
+extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y,
+                                   void* stream) {
+  int rc = check_desc_b(d);
+  if (rc) return rc;
+  if (!x || !wnk || !y) return FMI_ERR_BAD_ARG;
+  if (d->C % 32 != 0 || d->x_cstride % 8 != 0 || !aligned16b(x) || !aligned16b(wnk)) return FMI_ERR_UNSUPPORTED;
+  ConvGeom g{};
+  g.N = d->N; g.IH = d->H; g.IW = d->W; g.C = d->C; g.cstride = d->x_cstride;
+  g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
+  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = 1; g.xstep = 1;
+  g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
+  g.pad_mode = 0; g.vec = 1;
+  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
+  g.img_bs = 0;
+  ConvKB la{x, g};
+  ConvWKB lb{wnk, g, d->K, d->kh * d->kw};
+  ConvEpB ep{y, colscale, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, d->K, g.dGW, g.dG,
+             (d->K % 4 == 0 && d->y_cstride % 4 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0};
+  if (d->C % 64 == 0) return launch_conv_bf16<64>(la, lb, ep, g.Mdim(), d->K, g.Kdim(), (hipStream_t)stream);
+  return launch_conv_bf16<32>(la, lb, ep, g.Mdim(), d->K, g.Kdim(), (hipStream_t)stream);
+}
+
+/* dx = adjoint of the convolution described by d applied to dy; wck = weights packed [C][kh*kw][K] */
+extern "C" int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx,
+                                     void* stream) {
+  int rc = check_desc_b(d);
+  if (rc) return rc;
+  if (!dy || !wck || !dx) return FMI_ERR_BAD_ARG;
+  if (d->K % 32 != 0 || d->y_cstride % 8 != 0 || !aligned16b(dy) || !aligned16b(wck)) return FMI_ERR_UNSUPPORTED;
+  const int s = d->stride;
+  for (int py = 0; py < s; ++py) {
+    for (int px = 0; px < s; ++px) {
+      const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
+      if (GH <= 0 || GW <= 0) continue;
+      ConvGeom g{};
+      g.N = d->N; g.IH = d->OH; g.IW = d->OW; g.C = d->K; g.cstride = d->y_cstride;
+      g.GH = GH; g.GW = GW; g.S = 1;
+      g.kh0 = (py + d->pad) % s; g.kw0 = (px + d->pad) % s;
+      g.nty = g.kh0 < d->kh ? (d->kh - g.kh0 + s - 1) / s : 0;
+      g.ntx = g.kw0 < d->kw ? (d->kw - g.kw0 + s - 1) / s : 0;
+      g.dy0 = (py + d->pad - g.kh0) / s; g.dx0 = (px + d->pad - g.kw0) / s;
+      g.ystep = -1; g.xstep = -1; g.khstep = s; g.kwstep = s; g.kw = d->kw;
+      g.pad_mode = 0; g.vec = 1;
+      g.dGW = make_fastdiv(GW); g.dG = make_fastdiv(GH * GW); g.dC = make_fastdiv(g.C);
+      g.dntx = make_fastdiv(g.ntx > 0 ? g.ntx : 1);
+      g.img_bs = 0;
+      if (g.nty == 0 || g.ntx == 0) { g.nty = 0; g.ntx = 1; }
+      ConvKB la{dy, g};
+      ConvWKB lb{wck, g, d->C, d->kh * d->kw};
+      ConvEpB ep{dx, colscale, GH, GW, s, py, px, d->H, d->W, d->x_cstride, d->C, g.dGW, g.dG,
+                 (d->C % 4 == 0 && d->x_cstride % 4 == 0 && ((uintptr_t)dx & 7) == 0) ? 1 : 0};
+      rc = d->K % 64 == 0 ? launch_conv_bf16<64>(la, lb, ep, g.Mdim(), d->C, g.Kdim(), (hipStream_t)stream)
+                          : launch_conv_bf16<32>(la, lb, ep, g.Mdim(), d->C, g.Kdim(), (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  }
+  return FMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight packs: src fp32 [T][A][B] (the fp32 packs wf[tap][C][K] / wt[tap][K][C]) -> bf16 [B][T][A]
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_bta_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int T, int A, int B,
+                                                            int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int a = (int)(i % A);
+    const int64_t r = i / A;
+    const int t = (int)(r % T), b = (int)(r / T);
+    dst[i] = f2bf(src[((int64_t)t * A + a) * B + b]);
+  }
+}
+extern "C" int fmi_pack_weight_bf16(const float* src_tab, uint16_t* dst_bta, int T, int A, int B, void* stream) {
+  if (!src_tab || !dst_bta || T <= 0 || A <= 0 || B <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)T * A * B;
+  hipLaunchKernelGGL(pack_bta_bf16_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src_tab, dst_bta, T, A, B, total);
+  return fmi_launch_status();
+}
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient: dwf[tap][c][k] += sum over pixels x[pixel + tap][c] * dy[pixel][k]   (fp32 atomics across the pixel splits)
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct WgArgsB {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dwf;
+  ConvGeom g;  // forward geometry: anchors = output pixels, all kh*kw taps
+  int Kout, ycs, Mrows, P, kchunk;
+};
+
+// LDS image of one operand tile: [32-row group][64 pixels][32 rows] bf16 -- a wave instruction of the copy fills 16 pixels x 64
+// bytes of one group, so a thread's copies share ONE pixel decode; a transposed read of four pixel rows is 256 contiguous bytes.
+template <class T>
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n) {
+  constexpr int BM = T::BM, BN = T::BN, BK = 64;
+  constexpr int NGA = BM / 32, NGB = BN / 32;
+  constexpr int STAGE_B = (BM + BN) * BK * 2;  // bytes
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+  const ConvGeom& g = a.g;
+  const int k_begin = blockIdx.y * a.kchunk;
+  int k_end = k_begin + a.kchunk;
+  if (k_end > a.P) k_end = a.P;
+
+  const int kr = 16 * wid + (lane >> 2), cq = lane & 3;
+  // A copies: group j = rows m0 + 32 j .. +31 lie inside one tap (C % 32 == 0): wave-uniform tap, per-thread channel
+  int a_dy[NGA], a_dx[NGA];
+  int64_t a_off[NGA];
+#pragma unroll
+  for (int j = 0; j < NGA; ++j) {
+    const int row = m0 + 32 * j;
+    const int t = (int)fdiv((uint32_t)row, g.dC);
+    const int i = (int)fdiv((uint32_t)t, g.dntx), jx = t - i * g.ntx;
+    a_dy[j] = row < a.Mrows ? g.dy0 + i : -0x20000000;
+    a_dx[j] = g.dx0 + jx;
+    a_off[j] = ((int64_t)a_dy[j] * g.IW + a_dx[j]) * g.cstride + (row - t * g.C) + 8 * cq;
+  }
+  int b_col[NGB];
+#pragma unroll
+  for (int j = 0; j < NGB; ++j) {
+    const int col = n0 + 32 * j + 8 * cq;
+    b_col[j] = col < a.Kout ? col : -1;
+  }
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  auto glds16 = [&](const void* gp, uint32_t dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gp), "s"(dst)
+                 : "memory");
+  };
+  auto issue = [&](int k0, int st) {
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)st * STAGE_B + (uint32_t)wid * 1024u);
+    const uint32_t sb = sa + BM * BK * 2;
+    const int pix = k0 + kr;
+    const bool pv = pix < k_end;
+    const uint32_t n = fdiv((uint32_t)pix, g.dG);
+    const uint32_t rem = (uint32_t)pix - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    const int iy0 = (int)gy * g.S, ix0 = (int)gx * g.S;
+    const int64_t xb = ((int64_t)((int)n * g.IH + iy0) * g.IW + ix0) * g.cstride;
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) {
+      const bool ok = pv && (unsigned)(iy0 + a_dy[j]) < (unsigned)g.IH && (unsigned)(ix0 + a_dx[j]) < (unsigned)g.IW;
+      const void* gp = ok ? (const void*)(a.x + xb + a_off[j]) : (const void*)fmi_chunk_zero;
+      glds16(gp, sa + j * 4096);
+    }
+#pragma unroll
+    for (int j = 0; j < NGB; ++j) {
+      const bool ok = pv && b_col[j] >= 0;
+      const void* gp = ok ? (const void*)(a.dy + (int64_t)pix * a.ycs + b_col[j]) : (const void*)fmi_chunk_zero;
+      glds16(gp, sb + j * 4096);
+    }
+  };
+  // transposed fragment reads: lane 4q+p of a 16-lane group addresses pixel row q, rows 4p..4p+3 of the group's 16
+  const int i16 = lane & 15;
+  const uint32_t lbase = (uint32_t)((8 * lh + (i16 >> 2)) * 64 + 32 * ((lane >> 4) & 1) + 8 * (i16 & 3));
+  auto frag = [&](uint32_t img, int grp, int s) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const uint32_t ad = img + (uint32_t)grp * 4096u + lbase + (uint32_t)s * 1024u;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ad);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ad + 256u));
+    union {
+      s16x4 h[2];
+      bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+  };
+  auto compute = [&](int st) {
+    const uint32_t sa = lds0 + (uint32_t)st * STAGE_B, sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[T::TM], fb[T::TN];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) fa[i] = frag(sa, wm / 32 + i, s);
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) fb[j] = frag(sb, wn / 32 + j, s);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  if (nt > 0) issue(k_begin, 0);
+  int st = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) issue(k_begin + (t + 1) * BK, st ^ 1);
+    compute(st);
+    st ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= a.Mrows) continue;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        const int col = n0 + wn + j * 32 + l31;
+        if (col < a.Kout) atomicAdd(a.dwf + (int64_t)row * a.Kout + col, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+/* dwf[tap][C][K] (fp32, the layout of fmi_conv2d_wgrad_f32) += x^T dy; caller zeroes dwf */
+extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dwf, void* stream) {
+  int rc = check_desc_b(d);
+  if (rc) return rc;
+  if (!x || !dy || !dwf) return FMI_ERR_BAD_ARG;
+  if (d->C % 32 != 0 || d->K % 8 != 0 || d->x_cstride % 8 != 0 || d->y_cstride % 8 != 0 || !aligned16b(x) || !aligned16b(dy))
+    return FMI_ERR_UNSUPPORTED;
+  WgArgsB a{};
+  a.x = x; a.dy = dy; a.dwf = dwf;
+  ConvGeom& g = a.g;
+  g.N = d->N; g.IH = d->H; g.IW = d->W; g.C = d->C; g.cstride = d->x_cstride;
+  g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
+  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = 1; g.xstep = 1;
+  g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
+  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
+  a.Kout = d->K; a.ycs = d->y_cstride; a.Mrows = d->kh * d->kw * d->C; a.P = d->N * d->OH * d->OW;
+  const int bn = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
+  const int64_t tm = ceil_div64(a.Mrows, 128), tn = ceil_div64(d->K, bn);
+  int64_t ksplit = 2048 / (tm * tn);
+  const int64_t kmax = a.P / 1024;
+  if (ksplit > kmax) ksplit = kmax;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 65535) ksplit = 65535;
+  a.kchunk = (int)(ceil_div64(ceil_div64(a.P, ksplit), 64) * 64);
+  ksplit = ceil_div64(a.P, a.kchunk);
+  const dim3 grid((unsigned)(tm * tn), (unsigned)ksplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (bn == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x32>), grid, dim3(256), 0, st, a, (int)tn);
+  else if (bn == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x64>), grid, dim3(256), 0, st, a, (int)tn);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x128>), grid, dim3(256), 0, st, a, (int)tn);
+  return fmi_launch_status();
+}
+#endif  // FMI_HOST_EMU

@@ -1,0 +1,417 @@
+// bf16 activations of the StyleGAN2 decoder (configs C3 / C5): the bandwidth kernels around the bf16 convolutions of conv_bf16.hip.
+// Tensors are NHWC bf16 (uint16_t = raw bits); per-sample / per-channel factors, noise maps, biases and every reduction result
+// stay fp32.  One thread moves 8 channels (16 bytes) per access; C % 8 == 0 throughout.
+//   scale_channels      x * s[n][c]                       ModulatedConv2d: modulation / demodulation (model.py:244-252)
+//   noise_bias_act      lrelu(x + nw*noise + bias) * g    NoiseInjection + FusedLeakyReLU (model.py:282-294, op/fused_act.py:72-85)
+//   upfirdn2d_nhwc      Blur after the up-convolutions    (model.py:52-68, op/upfirdn2d.py:85-147)
+//   torgb               1x1 modulated conv C -> 3 without demodulation + bias + skip (model.py:349-369)
+#include "common.h"
+
+#ifndef FMI_HOST_EMU
+typedef uint16_t bf16_t;
+struct bf8 {
+  uint4 v;
+};
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf(float a, float b) {  // round to nearest even
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7fffu + ((ua >> 16) & 1u);
+  ub += 0x7fffu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf_lo(v.x), f[1] = bf_hi(v.x), f[2] = bf_lo(v.y), f[3] = bf_hi(v.y);
+  f[4] = bf_lo(v.z), f[5] = bf_hi(v.z), f[6] = bf_lo(v.w), f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf(f[0], f[1]), pack_bf(f[2], f[3]), pack_bf(f[4], f[5]), pack_bf(f[6], f[7]));
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
+}
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// y[n][p][c] = x[n][p][c] * s[n][c]
+__global__ void __launch_bounds__(256) scale_channels_bf16_kernel(const uint4* __restrict__ x, const float* __restrict__ s,
+                                                                  uint4* __restrict__ y, int64_t PC8, int C8, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t n = i / PC8;
+    float f[8], sc[8];
+    unpack8(x[i], f);
+    load8f(s + (n * C8 + c8) * 8, sc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= sc[e];
+    y[i] = pack8(f);
+  }
+}
+extern "C" int fmi_scale_channels_bf16(const uint16_t* x, const float* s, uint16_t* y, int N, int64_t P, int C, void* stream) {
+  if (!x || !s || !y || N <= 0 || P <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 8 != 0 || !al16(x) || !al16(y) || !al16(s)) return FMI_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)N * P * (C / 8);
+  hipLaunchKernelGGL(scale_channels_bf16_kernel, dim3(fmi_bw_grid(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)x, s, (uint4*)y, P * (C / 8), C / 8, total);
+  return fmi_launch_status();
+}
+
+// Shared shape of the per-channel reductions below: 256 threads = (256 / C8) rows x C8 channel chunks per pass; the threads that
+// own one chunk are combined through LDS and the block adds its 8 sums per chunk with fp32 atomics.
+__device__ __forceinline__ void chunk_reduce_atomic(float (&acc)[8], float* __restrict__ dst /*[C]*/, int C8, float (*part)[8]) {
+  const int RL = 256 / C8, cg = threadIdx.x % C8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if ((int)threadIdx.x < C8) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = part[threadIdx.x][e];
+    for (int l = 1; l < RL; ++l)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += part[l * C8 + cg][e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dst + 8 * cg + e, t[e]);
+  }
+  __syncthreads();
+}
+
+// gs[n][c] += sum_p g[n][p][c] * x[n][p][c]      (caller zeroes gs)
+__global__ void __launch_bounds__(256) scale_channels_gs_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ x,
+                                                                     float* __restrict__ gs, int64_t P, int C8, int64_t rows_per_block) {
+  __shared__ float part[256][8];
+  const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int n = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const uint4* gb = g + (int64_t)n * P * C8;
+  const uint4* xb = x + (int64_t)n * P * C8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    float a[8], b[8];
+    unpack8(gb[r * C8 + cg], a);
+    unpack8(xb[r * C8 + cg], b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], b[e], acc[e]);
+  }
+  chunk_reduce_atomic(acc, gs + (int64_t)n * C8 * 8, C8, part);
+}
+static bool c8_ok(int C) {
+  const int c8 = C / 8;
+  return C % 8 == 0 && c8 >= 1 && c8 <= 256 && (c8 & (c8 - 1)) == 0;
+}
+extern "C" int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, int N, int64_t P, int C, void* stream) {
+  if (!g || !x || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  if (!c8_ok(C) || !al16(g) || !al16(x)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = ceil_div64(P, 64);
+  if (blocks > 512) blocks = 512;
+  const int64_t rpb = ceil_div64(P, blocks);
+  blocks = ceil_div64(P, rpb);
+  hipLaunchKernelGGL(scale_channels_gs_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)g,
+                     (const uint4*)x, gs, P, C / 8, rpb);
+  return fmi_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// y = lrelu(x + bias[c] + nw * noise[p], alpha) * scale
+__global__ void __launch_bounds__(256) noise_bias_act_bf16_kernel(const uint4* __restrict__ x, const float* __restrict__ bias,
+                                                                  const float* __restrict__ noise, const float* __restrict__ nw,
+                                                                  uint4* __restrict__ y, int64_t total, int C8, float alpha, float scale) {
+  const float w = (noise && nw) ? nw[0] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / C8;
+    const int c8 = (int)(i - p * C8);
+    float f[8], b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unpack8(x[i], f);
+    if (bias) load8f(bias + 8 * c8, b);
+    const float nz = (noise && nw) ? w * noise[p] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = f[e] + b[e] + nz;
+      f[e] = (v > 0.f ? v : v * alpha) * scale;
+    }
+    y[i] = pack8(f);
+  }
+}
+extern "C" int fmi_noise_bias_act_bf16(const uint16_t* x, const float* bias, const float* noise, const float* nw, uint16_t* y,
+                                       int64_t pixels, int C, float alpha, float scale, void* stream) {
+  if (!x || !y || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 8 != 0 || !al16(x) || !al16(y) || !al16(bias)) return FMI_ERR_UNSUPPORTED;
+  const int64_t total = pixels * (C / 8);
+  hipLaunchKernelGGL(noise_bias_act_bf16_kernel, dim3(fmi_bw_grid(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
+                     bias, noise, nw, (uint4*)y, total, C / 8, alpha, scale);
+  return fmi_launch_status();
+}
+
+// backward: gx = g * scale * (y > 0 ? 1 : alpha);  gbias[c] += sum_p gx;  gnw += sum gx * noise[p]   (one pass; caller zeroes both)
+__global__ void __launch_bounds__(256) noise_bias_act_bwd_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y,
+                                                                      const float* __restrict__ noise, uint4* __restrict__ gx,
+                                                                      float* __restrict__ gnw, float* __restrict__ gbias, int64_t P,
+                                                                      int C8, float alpha, float scale, int64_t rows_per_block) {
+  __shared__ float part[256][8];
+  __shared__ float red[4];
+  const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float an = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    float a[8], b[8];
+    unpack8(g[r * C8 + cg], a);
+    unpack8(y[r * C8 + cg], b);
+    float rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = a[e] * scale * (b[e] > 0.f ? 1.f : alpha);
+      acc[e] += a[e];
+      rs += a[e];
+    }
+    if (noise) an = fmaf(rs, noise[r], an);
+    gx[r * C8 + cg] = pack8(a);
+  }
+  if (gbias) chunk_reduce_atomic(acc, gbias, C8, part);
+  if (noise && gnw) {
+    an = block_sum_256(an, red);
+    if (threadIdx.x == 0) atomicAdd(gnw, an);
+  }
+}
+extern "C" int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, uint16_t* gx, float* gnw,
+                                           float* gbias, int64_t pixels, int C, float alpha, float scale, void* stream) {
+  if (!g || !y || !gx || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (!c8_ok(C) || !al16(g) || !al16(y) || !al16(gx)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = ceil_div64(pixels, 64);
+  if (blocks > 2048) blocks = 2048;
+  const int64_t rpb = ceil_div64(pixels, blocks);
+  blocks = ceil_div64(pixels, rpb);
+  hipLaunchKernelGGL(noise_bias_act_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)g,
+                     (const uint4*)y, noise, (uint4*)gx, gnw, gbias, pixels, C / 8, alpha, scale, rpb);
+  return fmi_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// upfirdn2d on NHWC bf16, FIR form (up = down = 1, square kernel of 2..4 taps: the decoder's Blur and its gradient).  One thread =
+// (2 adjacent output pixels, 8 channels); the KH x (KW+1) window is read once with 16-byte loads; fp32 taps and accumulation.
+template <int KH, int KW>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_fir_bf16_kernel(const uint4* __restrict__ in, const float* __restrict__ kernel,
+                                                                      uint4* __restrict__ out, int in_h, int in_w, int C8, int out_h,
+                                                                      int out_w, int pad_x0, int pad_y0, int total) {
+  float kf[KH][KW];
+#pragma unroll
+  for (int a = 0; a < KH; ++a)
+#pragma unroll
+    for (int b = 0; b < KW; ++b) kf[a][b] = kernel[(KH - 1 - a) * KW + (KW - 1 - b)];
+  const int pw = (out_w + 1) >> 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int c8 = i % C8;
+    int r = i / C8;
+    const int px = r % pw;
+    r /= pw;
+    const int oy = r % out_h, n = r / out_h;
+    const int ox = 2 * px;
+    const int iy0 = oy - pad_y0, ix0 = ox - pad_x0;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = 0.f, a1[e] = 0.f;
+    const uint4* base = in + (int64_t)n * in_h * in_w * C8 + c8;
+#pragma unroll
+    for (int a = 0; a < KH; ++a) {
+      const int iy = iy0 + a;
+      if ((unsigned)iy >= (unsigned)in_h) continue;
+      const uint4* row = base + (int64_t)iy * in_w * C8;
+#pragma unroll
+      for (int b = 0; b <= KW; ++b) {
+        const int ix = ix0 + b;
+        if ((unsigned)ix >= (unsigned)in_w) continue;
+        float v[8];
+        unpack8(row[(int64_t)ix * C8], v);
+        if (b < KW) {
+          const float k0 = kf[a][b];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a0[e] = fmaf(v[e], k0, a0[e]);
+        }
+        if (b > 0) {
+          const float k1 = kf[a][b - 1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a1[e] = fmaf(v[e], k1, a1[e]);
+        }
+      }
+    }
+    uint4* o = out + ((int64_t)(n * out_h + oy) * out_w + ox) * C8 + c8;
+    o[0] = pack8(a0);
+    if (ox + 1 < out_w) o[C8] = pack8(a1);
+  }
+}
+extern "C" int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh,
+                                       int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                       void* stream) {
+  if (!in || !kernel || !out || N <= 0 || in_h <= 0 || in_w <= 0 || C <= 0 || kh <= 0 || kw <= 0) return FMI_ERR_BAD_ARG;
+  if (up_x != 1 || up_y != 1 || down_x != 1 || down_y != 1 || kh != kw || kh < 2 || kh > 4 || C % 8 != 0 || !al16(in) || !al16(out))
+    return FMI_ERR_UNSUPPORTED;  // the bf16 decoder only blurs; resampling stays on the fp32 entry
+  const int fh = in_h + pad_y0 + pad_y1 - kh, fw = in_w + pad_x0 + pad_x1 - kw;
+  if (fh < 0 || fw < 0) return FMI_ERR_BAD_ARG;
+  const int out_h = fh + 1, out_w = fw + 1;
+  const int64_t tv = (int64_t)N * out_h * ((out_w + 1) / 2) * (C / 8);
+  if (tv >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
+  const int grid = fmi_bw_grid(tv, 256);
+#define FIR_LAUNCH(K_)                                                                                                          \
+  hipLaunchKernelGGL((upfirdn2d_nhwc_fir_bf16_kernel<K_, K_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, \
+                     kernel, (uint4*)out, in_h, in_w, C / 8, out_h, out_w, pad_x0, pad_y0, (int)tv)
+  if (kh == 4) FIR_LAUNCH(4);
+  else if (kh == 3) FIR_LAUNCH(3);
+  else FIR_LAUNCH(2);
+#undef FIR_LAUNCH
+  return fmi_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ToRGB: out[n][p][o] = sum_c x[n][p][c] * w[o][c] * s[n][c] + bias[o] + skip[n][p][o],   o < 3, out / skip / bias fp32.
+// A pixel is spread over C8 = C/8 consecutive lanes (C8 <= 64, a power of two); the three partial dot products meet by butterfly.
+__global__ void __launch_bounds__(256) torgb_fwd_bf16_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ s, const float* __restrict__ bias,
+                                                             const float* __restrict__ skip, float* __restrict__ out, int64_t P, int C8,
+                                                             int64_t rows_per_block) {
+  const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int n = blockIdx.y, C = C8 * 8;
+  float wm[3][8];
+  {
+    float sc[8];
+    load8f(s + (int64_t)n * C + 8 * cg, sc);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      load8f(w + o * C + 8 * cg, wm[o]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wm[o][e] *= sc[e];
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const uint4* xb = x + (int64_t)n * P * C8;
+  for (int64_t rb = r0; rb < r1; rb += RL) {  // every lane runs every iteration (the butterfly needs the whole group)
+    const int64_t r = rb + rl;
+    float d[3] = {0.f, 0.f, 0.f};
+    if (r < r1) {
+      float v[8];
+      unpack8(xb[r * C8 + cg], v);
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[o] = fmaf(v[e], wm[o][e], d[o]);
+    }
+    for (int off = C8 >> 1; off > 0; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) d[o] += __shfl_xor(d[o], off, 64);
+    if (cg == 0 && r < r1) {
+      const int64_t q = ((int64_t)n * P + r) * 3;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) out[q + o] = d[o] + (bias ? bias[o] : 0.f) + (skip ? skip[q + o] : 0.f);
+    }
+  }
+}
+// backward: gx[n][p][c] = sum_o g[n][p][o] w[o][c] s[n][c];  gwm[n][o][c] += sum_p g[n][p][o] x[n][p][c];  gbias[o] += sum g
+__global__ void __launch_bounds__(256) torgb_bwd_bf16_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ s, const float* __restrict__ g,
+                                                             uint4* __restrict__ gx, float* __restrict__ gwm, float* __restrict__ gbias,
+                                                             int64_t P, int C8, int64_t rows_per_block) {
+  __shared__ float part[256][8];
+  const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int n = blockIdx.y, C = C8 * 8;
+  float wm[3][8];
+  {
+    float sc[8];
+    load8f(s + (int64_t)n * C + 8 * cg, sc);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      load8f(w + o * C + 8 * cg, wm[o]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wm[o][e] *= sc[e];
+    }
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const uint4* xb = x + (int64_t)n * P * C8;
+  uint4* gxb = gx + (int64_t)n * P * C8;
+  float acc[3][8];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[o][e] = 0.f;
+  float gb[3] = {0.f, 0.f, 0.f};
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    const int64_t q = ((int64_t)n * P + r) * 3;
+    const float g0 = g[q], g1 = g[q + 1], g2 = g[q + 2];
+    float v[8], o8[8];
+    unpack8(xb[r * C8 + cg], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o8[e] = g0 * wm[0][e] + g1 * wm[1][e] + g2 * wm[2][e];
+      acc[0][e] = fmaf(g0, v[e], acc[0][e]);
+      acc[1][e] = fmaf(g1, v[e], acc[1][e]);
+      acc[2][e] = fmaf(g2, v[e], acc[2][e]);
+    }
+    gxb[r * C8 + cg] = pack8(o8);
+    if (cg == 0) gb[0] += g0, gb[1] += g1, gb[2] += g2;
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) chunk_reduce_atomic(acc[o], gwm + ((int64_t)n * 3 + o) * C, C8, part);
+  if (gbias && cg == 0) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) atomicAdd(gbias + o, gb[o]);
+  }
+}
+// gw[o][c] = sum_n gwm[n][o][c] s[n][c];   gs[n][c] = sum_o gwm[n][o][c] w[o][c]
+__global__ void __launch_bounds__(256) torgb_finish_kernel(const float* __restrict__ gwm, const float* __restrict__ w,
+                                                           const float* __restrict__ s, float* __restrict__ gw, float* __restrict__ gs,
+                                                           int N, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 3 * C) {
+    const int c = i % C, o = i / C;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a = fmaf(gwm[((int64_t)n * 3 + o) * C + c], s[(int64_t)n * C + c], a);
+    gw[i] = a;
+  }
+  if (i < N * C) {
+    const int c = i % C, n = i / C;
+    float a = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) a = fmaf(gwm[((int64_t)n * 3 + o) * C + c], w[o * C + c], a);
+    gs[i] = a;
+  }
+}
+static bool torgb_ok(int C) {
+  const int c8 = C / 8;
+  return C % 8 == 0 && c8 >= 1 && c8 <= 64 && (c8 & (c8 - 1)) == 0;
+}
+extern "C" int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float* s, const float* bias, const float* skip, float* out,
+                                  int N, int64_t P, int C, void* stream) {
+  if (!x || !w || !s || !out || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  if (!torgb_ok(C) || !al16(x) || !al16(w) || !al16(s)) return FMI_ERR_UNSUPPORTED;
+  const int RL = 256 / (C / 8);
+  int64_t blocks = ceil_div64(P, 64);
+  if (blocks > 512) blocks = 512;
+  int64_t rpb = ceil_div64(ceil_div64(P, blocks), RL) * RL;
+  blocks = ceil_div64(P, rpb);
+  hipLaunchKernelGGL(torgb_fwd_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, w, s, bias, skip,
+                     out, P, C / 8, rpb);
+  return fmi_launch_status();
+}
+/* gwm: [N][3][C] fp32 workspace, zeroed by the caller; gbias [3] zeroed (may be NULL); gw [3][C], gs [N][C] are written */
+extern "C" int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* gwm, float* gw,
+                                  float* gs, float* gbias, int N, int64_t P, int C, void* stream) {
+  if (!x || !w || !s || !g || !gx || !gwm || !gw || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  if (!torgb_ok(C) || !al16(x) || !al16(gx) || !al16(w) || !al16(s)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = ceil_div64(P, 64);
+  if (blocks > 512) blocks = 512;
+  const int64_t rpb = ceil_div64(P, blocks);
+  blocks = ceil_div64(P, rpb);
+  hipLaunchKernelGGL(torgb_bwd_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, w, s, g,
+                     (uint4*)gx, gwm, gbias, P, C / 8, rpb);
+  const int tot = (N > 3 ? N : 3) * C;
+  hipLaunchKernelGGL(torgb_finish_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, gwm, w, s, gw, gs, N, C);
+  return fmi_launch_status();
+}
+#endif  // FMI_HOST_EMU

@@ -304,7 +304,138 @@ class _Conv2d(torch.autograd.Function):
 
 
 def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE):
+    if x.dtype == BF16:
+        if bias is not None or residual is not None or pad_mode or act:
+            raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding epilogue")
+        return _Conv2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad)
     return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act)
+
+
+# ---- bf16 activations (StyleGAN2 decoder of configs C3 / C5): fp32 master weights, bf16 copies packed per call ----
+BF16 = torch.bfloat16
+
+
+def _pack_bf16(src_tab: torch.Tensor) -> torch.Tensor:
+    """fp32 [T][A][B] -> bf16 [B][T][A] (reduction index contiguous): wf -> [K][taps][C], wt -> [C][taps][K]"""
+    t, a, b = src_tab.shape
+    out = torch.empty((b, t, a), device=src_tab.device, dtype=BF16)
+    _L().pack_weight_bf16(_p(src_tab), _p(out), t, a, b, _st())
+    return out
+
+
+class _Conv2dBF16(torch.autograd.Function):
+    """y = conv(x, W) on bf16 NHWC activations, fp32 accumulation; wf / wt are the fp32 packs (wf carries the weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, wt, kh, kw, stride, pad):
+        _chk(x, dtype=BF16)
+        _chk(wf, wt)
+        lib = _L()
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=BF16)
+        with _prof(f"conv_fwd_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * n * oh * ow * k * c * kh * kw):
+            lib.conv2d_fwd_bf16(C.byref(d), _p(x), _p(_pack_bf16(wf)), None, _p(y), _st())
+        ctx.save_for_backward(x, wf, wt)
+        ctx.cfg = (kh, kw, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _L()
+        x, wf, wt = ctx.saved_tensors
+        kh, kw, stride, pad = ctx.cfg
+        gy = gy.contiguous()
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
+        gx = gwf = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            with _prof(f"conv_dgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
+                lib.conv2d_dgrad_bf16(C.byref(d), _p(gy), _p(_pack_bf16(wt)), None, _p(gx), _st())
+        if ctx.needs_input_grad[1]:
+            gwf = _zeros_like(wf)
+            with _prof(f"conv_wgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
+                lib.conv2d_wgrad_bf16(C.byref(d), _p(x), _p(gy), _p(gwf), _st())
+        return gx, gwf, None, None, None, None, None
+
+
+class _ConvTranspose2dBF16(torch.autograd.Function):
+    """bf16 twin of _ConvTranspose2d: the adjoint of the stride-s conv view, sub-pixel phases inside the library."""
+
+    @staticmethod
+    def forward(ctx, x, wf, wt, kh, kw, stride, pad, out_pad):
+        _chk(x, dtype=BF16)
+        _chk(wf, wt)
+        lib = _L()
+        n, h, w, cs = x.shape
+        cb = wf.shape[1]
+        H = (h - 1) * stride - 2 * pad + kh + out_pad
+        W = (w - 1) * stride - 2 * pad + kw + out_pad
+        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        if (oh, ow) != (h, w):
+            raise FmiError("unsupported ConvTranspose2d geometry")
+        y = torch.empty((n, H, W, cb), device=x.device, dtype=BF16)
+        with _prof(f"convT_fwd_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
+            lib.conv2d_dgrad_bf16(C.byref(d), _p(x), _p(_pack_bf16(wt)), None, _p(y), _st())
+        ctx.save_for_backward(x, wf)
+        ctx.cfg, ctx.HW = (kh, kw, stride, pad), (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _L()
+        x, wf = ctx.saved_tensors
+        kh, kw, stride, pad = ctx.cfg
+        H, W = ctx.HW
+        gy = gy.contiguous()
+        n, h, w, cs = x.shape
+        cb = wf.shape[1]
+        d, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        gx = gwf = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            with _prof(f"convT_dgrad_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
+                lib.conv2d_fwd_bf16(C.byref(d), _p(gy), _p(_pack_bf16(wf)), None, _p(gx), _st())
+        if ctx.needs_input_grad[1]:
+            gwf = _zeros_like(wf)
+            with _prof(f"convT_wgrad_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
+                lib.conv2d_wgrad_bf16(C.byref(d), _p(gy), _p(x), _p(gwf), _st())
+        return gx, gwf, None, None, None, None, None, None
+
+
+class _ToRGB(torch.autograd.Function):
+    """out[n,p,o] = sum_c x[n,p,c] w[o,c] s[n,c] + bias[o] + skip[n,p,o]: the 1x1 modulated convolution of ToRGB without
+    demodulation (stylegan2/model.py:349-369) on bf16 activations; w [3,C], s [N,C], bias [3], skip / out [N,H,W,3] are fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, bias, skip):
+        _chk(x, dtype=BF16)
+        _chk(w, s, bias, skip)
+        n, h, wd, c = x.shape
+        out = torch.empty((n, h, wd, 3), device=x.device, dtype=torch.float32)
+        _L().torgb_fwd_bf16(_p(x), _p(w), _p(s), _p(bias), _p(skip), _p(out), n, h * wd, c, _st())
+        ctx.save_for_backward(x, w, s)
+        ctx.has = (bias is not None, skip is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, h, wd, c = x.shape
+        gx = torch.empty_like(x)
+        gwm = _zeros((n, 3, c), x.device)
+        gw, gs = torch.empty_like(w), torch.empty_like(s)
+        gb = _zeros(3, x.device) if ctx.has[0] else None
+        _L().torgb_bwd_bf16(_p(x), _p(w), _p(s), _p(g), _p(gx), _p(gwm), _p(gw), _p(gs), _p(gb), n, h * wd, c, _st())
+        return gx, gw, gs, gb, (g if ctx.has[1] else None)
+
+
+def torgb(x, w, s, bias=None, skip=None):
+    return _ToRGB.apply(x, w.contiguous(), s.contiguous(), bias, skip)
 
 
 _BIAS_GRAD_MEMO = [None, None, -1]  # (cotangent tensor, its column sums)
@@ -372,6 +503,10 @@ class _ConvTranspose2d(torch.autograd.Function):
 
 
 def conv_transpose2d(x, pw: PackedWeight, bias=None, residual=None, stride=2, pad=1, out_pad=1):
+    if x.dtype == BF16:
+        if bias is not None or residual is not None:
+            raise FmiError("the bf16 ConvTranspose2d has no bias / residual epilogue")
+        return _ConvTranspose2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad, out_pad)
     return _ConvTranspose2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, out_pad)
 
 
@@ -943,11 +1078,12 @@ class _ScaleChannels(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, s):
-        _chk(x, s)
+        _chk(x, dtype=x.dtype)
+        _chk(s)
         n, c = s.shape
         p = x.numel() // (n * c)
         y = torch.empty_like(x)
-        _L().scale_channels_f32(_p(x), _p(s), _p(y), n, p, c, _st())
+        (_L().scale_channels_bf16 if x.dtype == BF16 else _L().scale_channels_f32)(_p(x), _p(s), _p(y), n, p, c, _st())
         ctx.save_for_backward(x, s)
         return y
 
@@ -958,12 +1094,13 @@ class _ScaleChannels(torch.autograd.Function):
         n, c = s.shape
         p = x.numel() // (n * c)
         gx = gs = None
+        b16 = x.dtype == BF16
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _L().scale_channels_f32(_p(g), _p(s), _p(gx), n, p, c, _st())
+            (_L().scale_channels_bf16 if b16 else _L().scale_channels_f32)(_p(g), _p(s), _p(gx), n, p, c, _st())
         if ctx.needs_input_grad[1]:
             gs = _zeros_like(s)
-            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), n, p, c, _st())
+            (_L().scale_channels_gs_bf16 if b16 else _L().scale_channels_gs_f32)(_p(g), _p(x), _p(gs), n, p, c, _st())
         return gx, gs
 
 
@@ -1046,11 +1183,13 @@ class _NoiseBiasAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, noise, nw, alpha, scale):
-        _chk(x, bias, noise, nw)
+        _chk(x, dtype=x.dtype)
+        _chk(bias, noise, nw)
         c = x.shape[-1]
         y = torch.empty_like(x)
-        with _prof(f"bytes:noise_bias_act|{tuple(x.shape)}", 8.0 * x.numel()):
-            _L().noise_bias_act_f32(_p(x), _p(bias), _p(noise), _p(nw), _p(y), x.numel() // c, c, alpha, scale, _st())
+        with _prof(f"bytes:noise_bias_act|{tuple(x.shape)}", 2.0 * x.element_size() * x.numel()):
+            (_L().noise_bias_act_bf16 if x.dtype == BF16 else _L().noise_bias_act_f32)(
+                _p(x), _p(bias), _p(noise), _p(nw), _p(y), x.numel() // c, c, alpha, scale, _st())
         ctx.save_for_backward(y, noise)
         ctx.cfg = (alpha, scale, bias is not None, nw is not None)
         return y
@@ -1063,6 +1202,11 @@ class _NoiseBiasAct(torch.autograd.Function):
         c = y.shape[-1]
         gx = torch.empty_like(y)
         gnw = _zeros(1, y.device, torch.float32) if (has_nw and noise is not None) else None
+        if y.dtype == BF16:  # one pass: gx, the bias gradient and the noise-weight gradient
+            gb = _zeros(c, y.device, torch.float32) if (has_b and ctx.needs_input_grad[1]) else None
+            _L().noise_bias_act_bwd_bf16(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), _p(gb), y.numel() // c, c,
+                                         alpha, scale, _st())
+            return gx, gb, None, gnw, None, None
         _L().noise_bias_act_bwd_f32(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), y.numel() // c, c, alpha, scale, _st())
         gb = None
         if has_b and ctx.needs_input_grad[1]:
@@ -1081,15 +1225,16 @@ class _UpFirDnNHWC(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kernel, up, down, pad):
-        _chk(x, kernel)
+        _chk(x, dtype=x.dtype)
+        _chk(kernel)
         n, h, w, c = x.shape
         kh, kw = kernel.shape
         oh = (h * up + pad[0] + pad[1] - kh) // down + 1
         ow = (w * up + pad[0] + pad[1] - kw) // down + 1
-        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=x.dtype)
         # bandwidth kernel: the profile record carries algorithmic BYTES (in + out), tag prefix "bytes:"
-        with _prof(f"bytes:upfirdn2d|{n}x{h}x{w}x{c} up{up} down{down}", 4.0 * (x.numel() + y.numel())):
-            _L().upfirdn2d_nhwc_f32(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
+        with _prof(f"bytes:upfirdn2d|{n}x{h}x{w}x{c} up{up} down{down}", float(x.element_size()) * (x.numel() + y.numel())):
+            (_L().upfirdn2d_nhwc_bf16 if x.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, pad, (n, h, w, c), (oh, ow))
         return y
@@ -1103,9 +1248,9 @@ class _UpFirDnNHWC(torch.autograd.Function):
         gx0, gy0 = kw - pad[0] - 1, kh - pad[0] - 1
         gx1 = w * up - ow * down + pad[0] - up + 1
         gy1 = h * up - oh * down + pad[0] - up + 1
-        gx = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
-        with _prof(f"bytes:upfirdn2d_bwd|{n}x{h}x{w}x{c} up{up} down{down}", 4.0 * (g.numel() + gx.numel())):
-            _L().upfirdn2d_nhwc_f32(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
+        gx = torch.empty((n, h, w, c), device=g.device, dtype=g.dtype)
+        with _prof(f"bytes:upfirdn2d_bwd|{n}x{h}x{w}x{c} up{up} down{down}", float(g.element_size()) * (g.numel() + gx.numel())):
+            (_L().upfirdn2d_nhwc_bf16 if g.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
         return gx, None, None, None, None
 
 

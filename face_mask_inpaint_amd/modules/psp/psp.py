@@ -28,7 +28,10 @@ class pSp(nn.Module):
         self.set_opts(opts)
         self.opts.n_styles = int(math.log(self.opts.output_size, 2)) * 2 - 2
         self.encoder = self.set_encoder()
-        self.decoder = Generator(self.opts.output_size, 512, 8)
+        # opts.decoder_dtype ("bf16" / "fp32", this build's only extra option): bf16 synthesis network of configs C3 / C5
+        dd = getattr(self.opts, "decoder_dtype", "fp32")
+        dd = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}.get(dd, dd)
+        self.decoder = Generator(self.opts.output_size, 512, 8, compute_dtype=dd)
         if not opts.train_decoder:
             _freeze(self.decoder)
         self.face_pool = torch.nn.AdaptiveAvgPool2d((256, 256))

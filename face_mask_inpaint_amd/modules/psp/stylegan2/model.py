@@ -198,6 +198,10 @@ class ToRGB(nn.Module):
 
     def nhwc(self, x, style, skip=None):
         res = self.upsample.nhwc(skip) if skip is not None else None
+        if x.dtype == torch.bfloat16:  # bf16 decoder: dedicated bandwidth kernel, RGB / skip / bias stay fp32
+            m = self.conv
+            s = FF._Scale.apply(m.modulation(style), float(m.scale))
+            return FF.torgb(x, m.weight.view(3, m.in_channel), s, self.bias.view(3), res)
         return self.conv.nhwc(x, style, bias=self.bias.view(3), residual=res)  # conv + bias + upsampled skip in the epilogue
 
     def forward(self, input, style, skip=None):
@@ -205,8 +209,11 @@ class ToRGB(nn.Module):
 
 
 class Generator(nn.Module):
-    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01):
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01, compute_dtype=torch.float32):
         super().__init__()
+        # torch.bfloat16: the synthesis network keeps bf16 NHWC activations (fp32 accumulation, fp32 parameters / styles / noise /
+        # RGB skip path) -- the "bf16 decoder" of BASELINE.json configs C3 / C5; the reference itself has no such switch
+        self.compute_dtype = compute_dtype
         self.size = size
         self.style_dim = style_dim
         layers = [PixelNorm()]
@@ -272,6 +279,8 @@ class Generator(nn.Module):
             return latent[:, i].contiguous()
 
         out = FF.to_nhwc(self.input(latent))
+        if self.compute_dtype == torch.bfloat16:
+            out = out.to(torch.bfloat16)
         out = self.conv1.nhwc(out, lat(0), noise=noise[0])
         skip = self.to_rgb1.nhwc(out, lat(1))
         i = 1

@@ -104,6 +104,47 @@ int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const floa
 /* adjoint of a thin-INPUT 3x3 convolution (C <= 4, K = 4..64 a power of two, stride 1, pad 1, zeros): dx = thin-output convolution of
  * dy with flipped taps -- the input gradient of VGG16's first layer (loss.py:45-65); fmi_conv2d_dgrad_f32 routes to it by itself */
 int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);
+/* ------------------------------------------------------------------------
+ * bf16 convolution family (fp32 accumulate) for the StyleGAN2 decoder of the pSp path in configs C3 / C5
+ * (stylegan2/model.py:241-279: the grouped conv2d / conv_transpose2d of ModulatedConv2d.forward).  Activations are bf16 NHWC
+ * (uint16_t = raw bf16 bits), weights are bf16 copies of the fp32 packs with the REDUCTION index contiguous:
+ *   forward : wnk[K][kh*kw][C]   = fmi_pack_weight_bf16(wf[tap][C][K], T=taps, A=C, B=K)
+ *   adjoint : wck[C][kh*kw][K]   = fmi_pack_weight_bf16(wt[tap][K][C], T=taps, A=K, B=C)
+ * Needs the reduced channel count % 32 == 0, pixel pitches % 8 == 0, 16-byte aligned bases and zero padding
+ * (fmi_conv2d_bf16_supported); anything else returns FMI_ERR_UNSUPPORTED -- there is no silent fp32 detour.
+ * colscale (may be NULL): [N][out channels] fp32, multiplied into the result per (sample, channel) -- the demodulation factor.
+ * The adjoint handles stride > 1 by sub-pixel phases, i.e. it is also the ConvTranspose2d forward of the upsampling layers.
+ * ---------------------------------------------------------------------- */
+int fmi_conv2d_bf16_supported(const fmi_conv_desc* d);
+int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y, void* stream);
+int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx, void* stream);
+/* dwf[tap][C][K] (fp32, the layout of fmi_conv2d_wgrad_f32) += sum over pixels x (gathered) * dy; fp32 atomics across the pixel
+ * splits, caller zeroes dwf.  Operands reach the matrix cores through ds_read_b64_tr_b16 (the reduction index -- pixels -- is the
+ * slow index of both NHWC tensors).  Needs C % 32 == 0, K % 8 == 0. */
+int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dwf, void* stream);
+/* dst[b][t][a] = bf16(src[t][a][b]) */
+int fmi_pack_weight_bf16(const float* src_tab, uint16_t* dst_bta, int T, int A, int B, void* stream);
+/* bf16 NHWC activations around those convolutions (C % 8 == 0; per-sample / per-channel factors, noise, biases and all reduction
+ * results are fp32).  Same semantics as the _f32 entries of the same names:
+ *   scale_channels      y = x * s[n][c]                    (modulation / demodulation, model.py:244-252); _gs: gs[n][c] += sum_p g x
+ *   noise_bias_act      y = lrelu(x + bias[c] + nw*noise[p], alpha) * scale   (model.py:282-294,340-346; op/fused_act.py:72-85)
+ *   noise_bias_act_bwd  gx = g*scale*(y>0 ? 1 : alpha); gbias[c] += sum gx; gnw += sum gx*noise   (ONE pass; either may be NULL)
+ *   upfirdn2d_nhwc      the decoder's Blur and its gradient only: up = down = 1, square FIR of 2..4 taps (model.py:52-68)
+ *   torgb               out[n][p][o<3] = sum_c x w[o][c] s[n][c] + bias[o] + skip   (ToRGB, model.py:349-369; out / skip fp32)
+ *   torgb_bwd           gx (bf16), gw[3][C], gs[N][C], gbias[3] (+=, may be NULL); gwm = zeroed [N][3][C] fp32 workspace */
+int fmi_scale_channels_bf16(const uint16_t* x, const float* s, uint16_t* y, int N, int64_t P, int C, void* stream);
+int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, int N, int64_t P, int C, void* stream);
+int fmi_noise_bias_act_bf16(const uint16_t* x, const float* bias, const float* noise, const float* nw, uint16_t* y, int64_t pixels, int C,
+                            float alpha, float scale, void* stream);
+int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, uint16_t* gx, float* gnw, float* gbias,
+                                int64_t pixels, int C, float alpha, float scale, void* stream);
+int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh, int kw,
+                            int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float* s, const float* bias, const float* skip, float* out, int N,
+                       int64_t P, int C, void* stream);
+int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* gwm, float* gw, float* gs,
+                       float* gbias, int N, int64_t P, int C, void* stream);
+
 /* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
 int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);
 /* fold the gradient w.r.t. a reflection-padded tensor [N,H+2p,W+2p,C] back onto [N,H,W,C]. */

@@ -1,0 +1,195 @@
+"""bf16 decoder path (BASELINE.json configs C3 / C5: StyleGAN2 decoder in bf16, fp32 accumulate): every bf16 C-ABI entry against a
+torch fp32 evaluation of the SAME bf16-rounded operands, and the bf16 Generator against the fp32 Generator.
+
+Tolerances: the kernels accumulate in fp32 and round ONCE on output, so a bf16 result may differ from the fp32 evaluation by half a
+bf16 ulp of its magnitude (2^-9 relative) plus accumulation-order noise; fp32 reduction outputs (weight / bias / style gradients)
+are compared at fp32-accumulation tolerance scaled by the reduction length."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def FF():
+    from face_mask_inpaint_amd import functional
+
+    return functional
+
+
+def bf(t):
+    return t.to(BF)
+
+
+def close_bf16(got, ref, extra=0.0):
+    """|got - ref| <= 2^-8 |ref| + small absolute floor (one output rounding + accumulation noise)"""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = ref.abs() * 2.0 ** -8 + (1e-3 + extra) * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} elements off, worst {((got - ref).abs() - tol).max().item():.3e}"
+
+
+CONV_CASES = [(2, 64, 64, 12, 10, 3, 1, 1), (2, 32, 96, 9, 11, 3, 1, 1), (1, 128, 32, 16, 16, 1, 1, 0), (2, 64, 128, 8, 8, 3, 2, 0),
+              (2, 96, 64, 13, 9, 3, 2, 1), (3, 128, 256, 32, 32, 3, 1, 1), (1, 64, 40, 7, 5, 3, 1, 1), (2, 256, 64, 20, 20, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ks,stride,pad", CONV_CASES)
+def test_conv_bf16_entries(dev, FF, n, c, k, h, w, ks, stride, pad):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(c + k + h)
+    x = bf(torch.randn(n, c, h, w, generator=g))
+    wt_ = bf(torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5)
+    xr, wr = x.float().requires_grad_(True), wt_.float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    gy = bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy.float())
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ks, ks, stride, pad, 0)
+    assert lib.conv2d_bf16_supported(C.byref(d)) == (1 if k % 32 == 0 else 0)
+    wf = wt_.float().permute(2, 3, 1, 0).reshape(ks * ks, c, k).contiguous().to(dev)
+    wtp = wt_.float().permute(2, 3, 0, 1).reshape(ks * ks, k, c).contiguous().to(dev)
+    wnk, wck = FF._pack_bf16(wf), FF._pack_bf16(wtp)
+    assert torch.equal(wnk.cpu(), bf(wt_.float().permute(0, 2, 3, 1).reshape(k, ks * ks, c)))
+    xh, gh = x.permute(0, 2, 3, 1).contiguous().to(dev), gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    st = FF._st()
+    cs = (torch.rand(n, k, generator=g) + 0.5).to(dev)
+    y = torch.full((n, oh, ow, k), float("nan"), dtype=BF, device=dev)
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), st)
+    close_bf16(y, y_ref.detach().permute(0, 2, 3, 1))
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), st)
+    close_bf16(y, y_ref.detach().permute(0, 2, 3, 1) * cs.cpu().view(n, 1, 1, k))
+    if k % 32 == 0:
+        dx = torch.full((n, h, w, c), float("nan"), dtype=BF, device=dev)
+        lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), st)
+        close_bf16(dx, xr.grad.permute(0, 2, 3, 1))
+    dwf = torch.zeros(ks * ks, c, k, device=dev)
+    lib.conv2d_wgrad_bf16(C.byref(d), FF._p(xh), FF._p(gh), FF._p(dwf), st)
+    ref = wr.grad.permute(2, 3, 1, 0).reshape(ks * ks, c, k)
+    torch.testing.assert_close(dwf.cpu(), ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item() * (n * oh * ow) ** 0.5)
+
+
+def test_conv_bf16_rejects_unsupported(dev, FF):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    d, oh, ow = FF.conv_desc(1, 8, 8, 24, 32, 3, 3, 1, 1, 0)  # C % 32 != 0
+    assert lib.conv2d_bf16_supported(C.byref(d)) == 0
+    x = torch.zeros(1, 8, 8, 24, dtype=BF, device=dev)
+    w = torch.zeros(32, 9, 24, dtype=BF, device=dev)
+    y = torch.zeros(1, 8, 8, 32, dtype=BF, device=dev)
+    with pytest.raises(_lib.FmiError, match="unsupported"):
+        lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(w), None, FF._p(y), FF._st())
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 7, 64), (3, 16, 16, 512), (1, 5, 6, 32)])
+def test_bf16_elementwise(dev, FF, n, h, w, c):
+    g = torch.Generator().manual_seed(n * 31 + c)
+    x = bf(torch.randn(n, h, w, c, generator=g))
+    s = torch.rand(n, c, generator=g) + 0.5
+    gy = bf(torch.randn(n, h, w, c, generator=g))
+    # scale_channels
+    xd, sd = x.to(dev).requires_grad_(True), s.to(dev).requires_grad_(True)
+    y = FF.scale_channels(xd, sd)
+    assert y.dtype == BF
+    xr, sr = x.float().requires_grad_(True), s.clone().requires_grad_(True)
+    yr = xr * sr.view(n, 1, 1, c)
+    close_bf16(y, yr.detach())
+    y.backward(gy.to(dev))
+    yr.backward(gy.float())
+    close_bf16(xd.grad, xr.grad)
+    torch.testing.assert_close(sd.grad.cpu(), sr.grad, rtol=1e-4, atol=1e-4 * (h * w) ** 0.5)
+    # noise + bias + leaky relu
+    bias, noise, nw = torch.randn(c, generator=g), torch.randn(n, h, w, generator=g), torch.randn(1, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    bd, nwd = bias.to(dev).requires_grad_(True), nw.to(dev).requires_grad_(True)
+    y = FF.noise_bias_act(xd, bd, noise.to(dev), nwd, 0.2, 2 ** 0.5)
+    xr, br, nr = x.float().requires_grad_(True), bias.clone().requires_grad_(True), nw.clone().requires_grad_(True)
+    yr = F.leaky_relu(xr + br + nr * noise.unsqueeze(-1), 0.2) * 2 ** 0.5
+    close_bf16(y, yr.detach())
+    y.backward(gy.to(dev))
+    # reference gradient with the kernel's sign rule (sign of the bf16 OUTPUT)
+    gxr = gy.float() * 2 ** 0.5 * torch.where(y.detach().float().cpu() > 0, 1.0, 0.2)
+    close_bf16(xd.grad, gxr)
+    gq = xd.grad.float().cpu()  # the reductions sum the fp32 values BEFORE rounding: compare at bf16-rounding tolerance
+    torch.testing.assert_close(bd.grad.cpu(), gxr.sum(dim=(0, 1, 2)), rtol=2e-3, atol=2e-3 * (n * h * w) ** 0.5)
+    torch.testing.assert_close(nwd.grad.cpu(), (gxr * noise.unsqueeze(-1)).sum().view(1), rtol=2e-3, atol=2e-3 * (n * h * w * c) ** 0.5)
+    assert gq.shape == gxr.shape
+    # blur (upfirdn2d with up = down = 1) and its gradient
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = (k[:, None] * k[None, :]) / 64 * 4
+    xd = x.to(dev).requires_grad_(True)
+    y = FF.upfirdn2d_nhwc(xd, k2.to(dev), pad=(2, 1))
+    xr = x.float().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr.permute(0, 3, 1, 2), (2, 1, 2, 1)).reshape(n * c, 1, h + 3, w + 3), torch.flip(k2, [0, 1]).view(1, 1, 4, 4))
+    yr = yr.view(n, c, h, w).permute(0, 2, 3, 1)
+    close_bf16(y, yr.detach())
+    y.backward(gy.to(dev))
+    yr.backward(gy.float())
+    close_bf16(xd.grad, xr.grad)
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 9, 7, 64), (3, 16, 16, 512), (1, 5, 6, 32), (2, 33, 31, 128)])
+def test_torgb_bf16(dev, FF, n, h, w, c):
+    g = torch.Generator().manual_seed(n * 17 + c)
+    x = bf(torch.randn(n, h, w, c, generator=g))
+    wgt = torch.randn(3, c, generator=g) / c ** 0.5
+    s = torch.rand(n, c, generator=g) + 0.5
+    bias = torch.randn(3, generator=g)
+    skip = torch.randn(n, h, w, 3, generator=g)
+    gy = torch.randn(n, h, w, 3, generator=g)
+    leaves = [t.to(dev).requires_grad_(True) for t in (x, wgt, s, bias, skip)]
+    out = FF.torgb(*leaves)
+    refs = [t.clone().float().requires_grad_(True) for t in (x, wgt, s, bias, skip)]
+    xr, wr, sr, br, kr = refs
+    outr = torch.einsum("nhwc,oc,nc->nhwo", xr, wr, sr) + br + kr
+    torch.testing.assert_close(out.detach().cpu(), outr.detach(), rtol=1e-4, atol=1e-4)
+    out.backward(gy.to(dev))
+    outr.backward(gy)
+    close_bf16(leaves[0].grad, xr.grad)
+    red = (n * h * w) ** 0.5
+    torch.testing.assert_close(leaves[1].grad.cpu(), wr.grad, rtol=1e-4, atol=2e-5 * red)
+    torch.testing.assert_close(leaves[2].grad.cpu(), sr.grad, rtol=1e-4, atol=2e-5 * red)
+    torch.testing.assert_close(leaves[3].grad.cpu(), br.grad, rtol=1e-4, atol=2e-5 * red)
+    torch.testing.assert_close(leaves[4].grad.cpu(), kr.grad)
+
+
+def test_bf16_generator_tracks_fp32(dev):
+    """the bf16 synthesis network against the fp32 one (same parameters, styles, noise): image within bf16 accumulation of 14 layers,
+    parameter gradients of a mean-square loss within a few percent in norm"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator
+
+    torch.manual_seed(0)
+    g32 = Generator(64, 512, 2).to(dev)
+    g16 = Generator(64, 512, 2, compute_dtype=BF).to(dev)
+    g16.load_state_dict(g32.state_dict())
+    lat = torch.randn(2, g32.n_latent, 512, device=dev)
+    outs = []
+    for gen in (g32, g16):
+        img, _ = gen([lat], input_is_latent=True, randomize_noise=False)
+        assert img.dtype == torch.float32 and img.shape == (2, 3, 64, 64)
+        (img ** 2).mean().backward()
+        outs.append(img.detach())
+    a, b = outs
+    rel = (a - b).abs().max().item() / a.abs().max().item()
+    assert rel < 4e-2, rel
+    bad = []
+    for (k, p32), (_, p16) in zip(g32.named_parameters(), g16.named_parameters()):
+        if p32.grad is None:
+            assert p16.grad is None, k
+            continue
+        assert p16.grad is not None, k
+        num, den = (p32.grad - p16.grad).norm().item(), p32.grad.norm().item()
+        if num > 6e-2 * den + 1e-9:
+            bad.append((k, num / max(den, 1e-30)))
+    assert not bad, bad
