@@ -4,8 +4,9 @@ bench (that is bench.py, the PICNet-ref training step).  One MI355X, fp32, synth
 
   * train_psp step (GradualStyleEncoder IR-SE50 on src + ref, example-guided attention, StyleGAN2 256^2 decoder, masked-L2 +
     reference-L2 + W-norm loss, fused Adam), bs 16: images/s;
-  * ModulatedConv2d: fp32 MFMA utilisation of every convolution launch inside Generator forward / backward (north_star target:
-    >= 50 % MFMA utilisation; fp32 peak 157.3 TFLOP/s -- the bf16 decoder of configs[2] is not built yet);
+  * ModulatedConv2d: MFMA utilisation of every convolution launch inside Generator forward / backward (north_star target:
+    >= 50 % MFMA utilisation), for the fp32 decoder against the 157.3 TFLOP/s fp32 matrix peak AND for the bf16 decoder of
+    configs[2] ("bf16_decoder": bf16 activations, fp32 accumulate) against the 2516.6 TFLOP/s dense bf16 peak;
   * upfirdn2d / fused noise+bias+lrelu: achieved GB/s (algorithmic bytes = in + out) against the 8 TB/s HBM roofline, for the
     256^2 decoder and for the 1024^2 decoder of configs[4] (4 images per GPU).
 
@@ -18,6 +19,7 @@ import types
 import torch
 
 FP32_MFMA_PEAK = 157.3
+BF16_MFMA_PEAK = 2516.6  # 16 x the fp32 matrix rate (MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, ~2.5 PFLOP/s dense)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -35,14 +37,14 @@ def synth(n, dev, seed=1234):
     return x.to(dev), ref.to(dev), y.to(dev), m.to(dev)
 
 
-def summarise(recs):
-    conv = [(t, f, s.elapsed_time(e)) for t, f, s, e in recs if not t.startswith("bytes:")]
+def summarise(recs, peak=FP32_MFMA_PEAK, only_bf16=False):
+    conv = [(t, f, s.elapsed_time(e)) for t, f, s, e in recs if not t.startswith("bytes:") and (not only_bf16 or "_bf16|" in t)]
     byt = [(t, f, s.elapsed_time(e)) for t, f, s, e in recs if t.startswith("bytes:")]
     out = {}
     if conv:
         fl, ms = sum(f for _, f, _ in conv), sum(m for _, _, m in conv)
         out["mfma"] = {"launches": len(conv), "algorithmic_tflop": round(fl / 1e12, 3), "kernel_ms": round(ms, 3),
-                       "tflops": round(fl / ms / 1e9, 2), "utilisation_fp32": round(fl / ms / 1e9 / FP32_MFMA_PEAK, 4)}
+                       "tflops": round(fl / ms / 1e9, 2), "peak_tflops": peak, "utilisation": round(fl / ms / 1e9 / peak, 4)}
     for key in ("upfirdn2d", "noise_bias_act"):
         sel = [(f, m) for t, f, m in byt if t.startswith("bytes:" + key)]
         if sel:
@@ -52,12 +54,12 @@ def summarise(recs):
     return out
 
 
-def decoder_profile(size, n, dev, backward=True):
+def decoder_profile(size, n, dev, backward=True, dtype=torch.float32):
     from face_mask_inpaint_amd import functional as FF
     from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator
 
     torch.manual_seed(0)
-    gen = Generator(size, 512, 8).to(dev)
+    gen = Generator(size, 512, 8, compute_dtype=dtype).to(dev)
     lat = torch.randn(n, gen.n_latent, 512, device=dev, requires_grad=True)
 
     def run():
@@ -74,6 +76,8 @@ def decoder_profile(size, n, dev, backward=True):
     recs, FF.PROFILE = FF.PROFILE, None
     del gen
     torch.cuda.empty_cache()
+    if dtype == torch.bfloat16:  # ModulatedConv2d launches only (the EqualLinear style GEMMs stay fp32)
+        return summarise(recs, BF16_MFMA_PEAK, only_bf16=True)
     return summarise(recs)
 
 
@@ -123,49 +127,58 @@ def main():
     from face_mask_inpaint_amd.modules.psp.psp import pSp
     from face_mask_inpaint_amd.optim import FusedAdam
 
-    torch.manual_seed(0)
-    opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
-                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True)
-    net = pSp(opts).to(dev).train()
-    net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
-    crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
-                                         w_norm_lambda=0.005, start_from_latent_avg=True))
-    opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
-    x, ref, y, m = synth(args.batch, dev)
+    def train_leg(decoder_dtype):
+        torch.manual_seed(0)
+        opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
+                                     stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype=decoder_dtype)
+        net = pSp(opts).to(dev).train()
+        net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
+        crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
+                                             w_norm_lambda=0.005, start_from_latent_avg=True))
+        opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
+        x, ref, y, m = synth(args.batch, dev)
 
-    def step():
-        y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True)
-        loss, _, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
+        def step():
+            y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True)
+            loss, _, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
 
-    for _ in range(args.warmup):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(loss).item()
+        FF.PROFILE = []
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert torch.isfinite(loss).item()
-    FF.PROFILE = []
-    step()
-    torch.cuda.synchronize()
-    recs, FF.PROFILE = FF.PROFILE, None
-    whole = summarise(recs)
-    del net, opt
-    torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        recs, FF.PROFILE = FF.PROFILE, None
+        del net, opt
+        torch.cuda.empty_cache()
+        return dt, summarise(recs)
+
+    dt, whole = train_leg("fp32")
+    dt16, whole16 = train_leg("bf16")
     out = {"metric": "train_psp images/sec (fp32, encoder trained, decoder frozen, LPIPS/ID off)", "value": round(args.batch * args.steps / dt, 2), "unit": "images/s",
            "n_gpus": 1, "batch": args.batch, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 2), "dtype": "f32", "data": "synthetic",
            "whole_step": whole,
+           "bf16_decoder": {"config": "BASELINE.json configs[2]: StyleGAN2 256^2 decoder in bf16 (fp32 accumulate), encoder fp32, bs %d" % args.batch,
+                            "images_per_s": round(args.batch * args.steps / dt16, 2), "ms_per_step": round(dt16 / args.steps * 1e3, 2),
+                            "whole_step": whole16,
+                            "decoder_256_fwd_bwd": decoder_profile(256, args.batch, dev, dtype=torch.bfloat16)},
            "decoder_256_fwd_bwd": decoder_profile(256, args.batch, dev),
            "native_ops_planar": native_op_bandwidth(dev),
-           "peaks": {"fp32_mfma_tflops": FP32_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}}
+           "peaks": {"fp32_mfma_tflops": FP32_MFMA_PEAK, "bf16_mfma_tflops": BF16_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}}
     if not args.skip_1024:
         out["decoder_1024_fwd_bs4"] = decoder_profile(1024, 4, dev, backward=False)
         out["decoder_1024_fwd_bwd_bs4"] = decoder_profile(1024, 4, dev, backward=True)
+        out["bf16_decoder"]["decoder_1024_fwd_bwd_bs4"] = decoder_profile(1024, 4, dev, backward=True, dtype=torch.bfloat16)
     print(json.dumps(out), flush=True)
 
 
