@@ -114,16 +114,27 @@ struct ConvEpB {  // rows = anchors, written at (gy*OS+py, gx*OS+px) of the bf16
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward / adjoint kernel
 // ---------------------------------------------------------------------------------------------------------------------------
-template <class T, int BK>
-__global__ void __launch_bounds__(256) conv_bf16_kernel(ConvKB la, ConvWKB lb, ConvEpB ep, int M, int N, int K, int tiles_n) {
-  constexpr int BM = T::BM, BN = T::BN;
+// tiles of the bf16 kernels: WM x WN waves (4 or 8), each TM x TN accumulators of 32 x 32
+template <int WM_, int WN_, int TM_, int TN_>
+struct TileB {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+};
+using TB128x128 = TileB<2, 2, 2, 2>;
+using TB128x64 = TileB<2, 2, 2, 1>;
+using TB128x32 = TileB<4, 1, 1, 1>;
+using TB64x64 = TileB<2, 2, 1, 1>;
+using TB64x128 = TileB<2, 2, 1, 2>;
+using TB256x256 = TileB<2, 4, 4, 2>;  // 8 waves, 128 x 64 per wave: 128 FLOP per staged byte (the 128 x 128 tile: 64 -> L2-rate bound)
+
+template <class T, int BK, int NST = 2>
+__global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb, ConvEpB ep, int M, int N, int K, int tiles_n) {
+  constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
   constexpr int CPR = BK / 8;            // 16-byte chunks per image row
-  constexpr int RPI = 64 / CPR;          // image rows one wave instruction (1 KiB) fills
-  constexpr int NLA = (BM * CPR + 255) / 256, NLB = (BN * CPR + 255) / 256;
+  constexpr int NLA = (BM * CPR + NT - 1) / NT, NLB = (BN * CPR + NT - 1) / NT;
   constexpr int STAGE = (BM + BN) * BK;  // bf16 elements
-  constexpr int NST = 2;
+  constexpr int DEPTH = NST - 1;  // tiles copied ahead of the one computed
   __shared__ __attribute__((aligned(1024))) bf16_t lds[NST * STAGE];
-  (void)RPI;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -138,17 +149,19 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(ConvKB la, ConvWKB lb, C
   ConvWKB::DCtx db[NLB];
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
-    const int p = j * 256 + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
+    const int p = j * NT + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
     da[j] = la.dprep(m0 + x, c * 8);
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
-    const int p = j * 256 + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
+    const int p = j * NT + tid, x = p / CPR, c = (p % CPR) ^ swz(x);
     db[j] = lb.dprep(n0 + x, c * 8);
   }
   // images smaller than 256 chunks are filled by the first waves only (wave-uniform)
-  const int na_w = (BM * CPR % 256 == 0) ? NLA : (wid * 64 < BM * CPR ? 1 : 0);
-  const int nb_w = (BN * CPR % 256 == 0) ? NLB : (wid * 64 < BN * CPR ? 1 : 0);
+  static_assert(BM * CPR % NT == 0 || BM * CPR < NT, "A image: whole instructions per thread, or fewer chunks than threads");
+  static_assert(BN * CPR % NT == 0 || BN * CPR < NT, "B image: whole instructions per thread, or fewer chunks than threads");
+  const int na_w = (BM * CPR % NT == 0) ? NLA : (wid * 64 < BM * CPR ? 1 : 0);
+  const int nb_w = (BN * CPR % NT == 0) ? NLB : (wid * 64 < BN * CPR ? 1 : 0);
 
   f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -173,41 +186,40 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(ConvKB la, ConvWKB lb, C
     const ConvWKB::Tile tb = lb.tile(k0);
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
-      if (BM * CPR % 256 != 0 && !na_w) break;
+      if (BM * CPR % NT != 0 && !na_w) break;
       const void* g = la.chunk(da[j], ta);
       if (!g) g = fmi_chunk_zero;
-      glds16(g, sa + j * 4096);
+      glds16(g, sa + j * NT * 16);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
-      if (BN * CPR % 256 != 0 && !nb_w) break;
+      if (BN * CPR % NT != 0 && !nb_w) break;
       const void* g = lb.chunk(db[j], tb);
       if (!g) g = fmi_chunk_zero;
-      glds16(g, sb + j * 4096);
+      glds16(g, sb + j * NT * 16);
     }
   };
   auto compute = [&](int st) {
     const bf16_t* sa = lds + st * STAGE;
     const bf16_t* sb = sa + BM * BK;
-    bf16x8 fa[T::TM][BK / 16], fb[T::TN][BK / 16];
 #pragma unroll
-    for (int i = 0; i < T::TM; ++i) {
-      const int r = wm + i * 32 + l31, sw = swz(r);
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[T::TM], fb[T::TN];
 #pragma unroll
-      for (int s = 0; s < BK / 16; ++s) fa[i][s] = *reinterpret_cast<const bf16x8*>(sa + r * BK + (((2 * s + lh) ^ sw) << 3));
-    }
+      for (int i = 0; i < T::TM; ++i) {
+        const int r = wm + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + r * BK + (((2 * s + lh) ^ swz(r)) << 3));
+      }
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j) {
-      const int r = wn + j * 32 + l31, sw = swz(r);
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) fb[j][s] = *reinterpret_cast<const bf16x8*>(sb + r * BK + (((2 * s + lh) ^ sw) << 3));
-    }
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s)
+      for (int j = 0; j < T::TN; ++j) {
+        const int r = wn + j * 32 + l31;
+        fb[j] = *reinterpret_cast<const bf16x8*>(sb + r * BK + (((2 * s + lh) ^ swz(r)) << 3));
+      }
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
   };
   auto wait_copies = [&](int n) {
     switch (n) {
@@ -219,22 +231,32 @@ __global__ void __launch_bounds__(256) conv_bf16_kernel(ConvKB la, ConvWKB lb, C
       case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
   const int nt = (K + BK - 1) / BK;
-  const int nw = (BM * CPR % 256 == 0 && BN * CPR % 256 == 0) ? NLA + NLB : na_w + nb_w;
-  if (nt > 0) issue(0, 0);
-  int st = 0;
+  const int nw = (BM * CPR % NT == 0 && BN * CPR % NT == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
+#pragma unroll
+  for (int p = 0; p < DEPTH; ++p)
+    if (p < nt) issue(p * BK, p);
+  int st = 0, stn = DEPTH;
   for (int t = 0; t < nt; ++t) {
-    wait_copies(0);  // with a two-stage ring only tile t is in flight here
+    int pend = nt - 1 - t;  // tile t must have landed; up to DEPTH-1 newer tiles may stay in flight
+    if (pend > DEPTH - 1) pend = DEPTH - 1;
+    wait_copies(pend * nw);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 1 < nt) issue((t + 1) * BK, st ^ 1);
+    if (t + DEPTH < nt) issue((t + DEPTH) * BK, stn);
     compute(st);
-    st ^= 1;
+    st = st == NST - 1 ? 0 : st + 1;
+    stn = stn == NST - 1 ? 0 : stn + 1;
   }
-  (void)nw;
 
   // epilogue: 4 x 4 transpose inside each quad of lanes -> one row, four consecutive columns per lane, 8-byte bf16 stores
   const int c = l31 & 3, colq = l31 & ~3;
@@ -278,18 +300,22 @@ static int launch_conv_bf16(const ConvKB& la, const ConvWKB& lb, const ConvEpB& 
   do {                                                                                                                            \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                                     \
     if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                       \
-    hipLaunchKernelGGL((conv_bf16_kernel<TILE, BK>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn); \
+    hipLaunchKernelGGL((conv_bf16_kernel<TILE, BK>), dim3((unsigned)(tm * tn)), dim3(TILE::NT), 0, st, la, lb, ep, M, N, K, (int)tn); \
   } while (0)
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn); };
+  static const int tile_dbg = getenv("FMI_BF16_TILE") ? atoi(getenv("FMI_BF16_TILE")) : 0;  // debug: 1 = never use the 8-wave tiles
   if (N <= 32) {
-    FMI_LAUNCH_B(Tile128x32);
+    FMI_LAUNCH_B(TB128x32);
   } else if (N <= 64) {
-    if (wgs(128, 64) >= 384) FMI_LAUNCH_B(Tile128x64);
-    else FMI_LAUNCH_B(Tile64x64);
+    if (wgs(128, 64) >= 384) FMI_LAUNCH_B(TB128x64);
+    else FMI_LAUNCH_B(TB64x64);
   } else {
-    if (wgs(128, 128) >= 512) FMI_LAUNCH_B(Tile128x128);
-    else if (wgs(64, 128) >= 256) FMI_LAUNCH_B(Tile64x128);
-    else FMI_LAUNCH_B(Tile64x64);
+    // measured (512 -> 512 at 64^2, 256 -> 256 at 128^2): 256x256 / 2 stages 870-990 TFLOP/s, 128x128 690-820, 256x256 with BK 32 and
+    // four stages 780-900; for N = 128 the 256x128 tile loses to 128x128 (660 vs 690)
+    if (BK == 64 && tile_dbg != 1 && N > 128 && wgs(256, 256) >= 200) FMI_LAUNCH_B(TB256x256);
+    else if (wgs(128, 128) >= 512) FMI_LAUNCH_B(TB128x128);
+    else if (wgs(64, 128) >= 256) FMI_LAUNCH_B(TB64x128);
+    else FMI_LAUNCH_B(TB64x64);
   }
 #undef FMI_LAUNCH_B
   return fmi_launch_status();
@@ -406,9 +432,11 @@ struct WgArgsB {
 // LDS image of one operand tile: [32-row group][64 pixels][32 rows] bf16 -- a wave instruction of the copy fills 16 pixels x 64
 // bytes of one group, so a thread's copies share ONE pixel decode; a transposed read of four pixel rows is 256 contiguous bytes.
 template <class T>
-__global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n) {
+__global__ void __launch_bounds__(T::NT) wgrad_bf16_kernel(WgArgsB a, int tiles_n) {
   constexpr int BM = T::BM, BN = T::BN, BK = 64;
-  constexpr int NGA = BM / 32, NGB = BN / 32;
+  constexpr int WPP = T::NT / 256;  // waves per 16-pixel block of the tile (8-wave tiles: two, each filling every other row group)
+  constexpr int NGA = BM / 32 / WPP, NGB = BN / 32 / WPP;
+  static_assert(NGA >= 1 && NGB >= 1, "every wave copies at least one group of each operand");
   constexpr int STAGE_B = (BM + BN) * BK * 2;  // bytes
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -422,13 +450,13 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n)
   int k_end = k_begin + a.kchunk;
   if (k_end > a.P) k_end = a.P;
 
-  const int kr = 16 * wid + (lane >> 2), cq = lane & 3;
+  const int kr = 16 * (wid & 3) + (lane >> 2), cq = lane & 3, gsel = wid >> 2;
   // A copies: group j = rows m0 + 32 j .. +31 lie inside one tap (C % 32 == 0): wave-uniform tap, per-thread channel
   int a_dy[NGA], a_dx[NGA];
   int64_t a_off[NGA];
 #pragma unroll
   for (int j = 0; j < NGA; ++j) {
-    const int row = m0 + 32 * j;
+    const int row = m0 + 32 * (j * WPP + gsel);
     const int t = (int)fdiv((uint32_t)row, g.dC);
     const int i = (int)fdiv((uint32_t)t, g.dntx), jx = t - i * g.ntx;
     a_dy[j] = row < a.Mrows ? g.dy0 + i : -0x20000000;
@@ -438,7 +466,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n)
   int b_col[NGB];
 #pragma unroll
   for (int j = 0; j < NGB; ++j) {
-    const int col = n0 + 32 * j + 8 * cq;
+    const int col = n0 + 32 * (j * WPP + gsel) + 8 * cq;
     b_col[j] = col < a.Kout ? col : -1;
   }
 
@@ -459,7 +487,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n)
                  : "memory");
   };
   auto issue = [&](int k0, int st) {
-    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)st * STAGE_B + (uint32_t)wid * 1024u);
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)st * STAGE_B + (uint32_t)(wid & 3) * 1024u + (uint32_t)gsel * 4096u);
     const uint32_t sb = sa + BM * BK * 2;
     const int pix = k0 + kr;
     const bool pv = pix < k_end;
@@ -473,13 +501,13 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(WgArgsB a, int tiles_n)
     for (int j = 0; j < NGA; ++j) {
       const bool ok = pv && (unsigned)(iy0 + a_dy[j]) < (unsigned)g.IH && (unsigned)(ix0 + a_dx[j]) < (unsigned)g.IW;
       const void* gp = ok ? (const void*)(a.x + xb + a_off[j]) : (const void*)fmi_chunk_zero;
-      glds16(gp, sa + j * 4096);
+      glds16(gp, sa + j * WPP * 4096);
     }
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {
       const bool ok = pv && b_col[j] >= 0;
       const void* gp = ok ? (const void*)(a.dy + (int64_t)pix * a.ycs + b_col[j]) : (const void*)fmi_chunk_zero;
-      glds16(gp, sb + j * 4096);
+      glds16(gp, sb + j * WPP * 4096);
     }
   };
   // transposed fragment reads: lane 4q+p of a 16-lane group addresses pixel row q, rows 4p..4p+3 of the group's 16
@@ -555,6 +583,8 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
   g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
   a.Kout = d->K; a.ycs = d->y_cstride; a.Mrows = d->kh * d->kw * d->C; a.P = d->N * d->OH * d->OW;
+  // the 8-wave 256x256 tile (the kernel takes it: WPP = 2) measured SLOWER here than 128x128 (574 vs 770 TFLOP/s at 512 -> 512, 64^2):
+  // one workgroup per CU and a 16-accumulator atomic epilogue per split leave the CU idle between tiles
   const int bn = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
   const int64_t tm = ceil_div64(a.Mrows, 128), tn = ceil_div64(d->K, bn);
   int64_t ksplit = 2048 / (tm * tn);
@@ -566,9 +596,9 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   ksplit = ceil_div64(a.P, a.kchunk);
   const dim3 grid((unsigned)(tm * tn), (unsigned)ksplit);
   hipStream_t st = (hipStream_t)stream;
-  if (bn == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x32>), grid, dim3(256), 0, st, a, (int)tn);
-  else if (bn == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x64>), grid, dim3(256), 0, st, a, (int)tn);
-  else hipLaunchKernelGGL((wgrad_bf16_kernel<Tile128x128>), grid, dim3(256), 0, st, a, (int)tn);
+  if (bn == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<TB128x32>), grid, dim3(256), 0, st, a, (int)tn);
+  else if (bn == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<TB128x64>), grid, dim3(256), 0, st, a, (int)tn);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<TB128x128>), grid, dim3(256), 0, st, a, (int)tn);
   return fmi_launch_status();
 }
 #endif  // FMI_HOST_EMU
