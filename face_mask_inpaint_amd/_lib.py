@@ -50,12 +50,12 @@ SIGNATURES = {
     "fmi_conv2d_wgrad_bf16": [PD, vp, vp, vp, vp],
     "fmi_pack_weight_bf16": [vp, vp, i32, i32, i32, vp],
     "fmi_scale_channels_bf16": [vp, vp, vp, i32, i64, i32, vp],
-    "fmi_scale_channels_gs_bf16": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_scale_channels_gs_bf16": [vp, vp, vp, vp, i64, i32, i64, i32, vp],
     "fmi_noise_bias_act_bf16": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
-    "fmi_noise_bias_act_bwd_bf16": [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
+    "fmi_noise_bias_act_bwd_bf16": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, f32, f32, vp],
     "fmi_upfirdn2d_nhwc_bf16": [vp, vp, vp] + [i32] * 14 + [vp],
     "fmi_torgb_fwd_bf16": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
-    "fmi_torgb_bwd_bf16": [vp] * 9 + [i32, i64, i32, vp],
+    "fmi_torgb_bwd_bf16": [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i64, i32, vp],
     "fmi_bias_grad_f32": [vp, i64, i32, i32, vp, vp],
     "fmi_reflect_pad_fold_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_weight_prepare_f32": [vp, i32, vp],

@@ -58,8 +58,10 @@ extern "C" int fmi_scale_channels_bf16(const uint16_t* x, const float* s, uint16
 }
 
 // Shared shape of the per-channel reductions below: 256 threads = (256 / C8) rows x C8 channel chunks per pass; the threads that
-// own one chunk are combined through LDS and the block adds its 8 sums per chunk with fp32 atomics.
-__device__ __forceinline__ void chunk_reduce_atomic(float (&acc)[8], float* __restrict__ dst /*[C]*/, int C8, float (*part)[8]) {
+// own one chunk are combined through LDS.  The block's sums are STORED as row `dst` of a partials workspace: thousands of fp32 atomics on a few hundred
+// addresses serialise in L2 (measured: 0.2 ms per launch for 2048 blocks x 128 channels, 4x the streaming time of the pass itself);
+// sum_parts_kernel adds the rows afterwards -- deterministic, and nothing has to be zeroed.
+__device__ __forceinline__ void chunk_reduce_store(float (&acc)[8], float* __restrict__ dst /*[C]*/, int C8, float (*part)[8]) {
   const int RL = 256 / C8, cg = threadIdx.x % C8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[threadIdx.x][e] = acc[e];
@@ -71,15 +73,44 @@ __device__ __forceinline__ void chunk_reduce_atomic(float (&acc)[8], float* __re
     for (int l = 1; l < RL; ++l)
 #pragma unroll
       for (int e = 0; e < 8; ++e) t[e] += part[l * C8 + cg][e];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dst + 8 * cg + e, t[e]);
+    *reinterpret_cast<float4*>(dst + 8 * cg) = make_float4(t[0], t[1], t[2], t[3]);
+    *reinterpret_cast<float4*>(dst + 8 * cg + 4) = make_float4(t[4], t[5], t[6], t[7]);
   }
   __syncthreads();
 }
+// out[g][i] = sum_{p < nparts} ws[(g * nparts + p) * width + i]
+__global__ void __launch_bounds__(256) sum_parts_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width,
+                                                        int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t g = t / width;
+  const int i = (int)(t - g * width);
+  const float* p = ws + g * nparts * (int64_t)width + i;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = 0;
+  for (; q + 3 < nparts; q += 4) {
+    a0 += p[(int64_t)q * width], a1 += p[(int64_t)(q + 1) * width], a2 += p[(int64_t)(q + 2) * width], a3 += p[(int64_t)(q + 3) * width];
+  }
+  for (; q < nparts; ++q) a0 += p[(int64_t)q * width];
+  out[t] = (a0 + a1) + (a2 + a3);
+}
+static void launch_sum_parts(const float* ws, float* out, int nparts, int width, int64_t groups, hipStream_t st) {
+  const int64_t total = groups * width;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, ws, out, nparts, width, total);
+}
+// how many row blocks a reduction pass uses: enough to fill the chip, at most what the workspace holds (width floats per block)
+static int64_t parts_for(int64_t rows, int64_t groups, int64_t width, int64_t ws_floats) {
+  int64_t b = ceil_div64(rows, 64);
+  const int64_t want = ceil_div64(2048, groups);
+  if (b > want) b = want;
+  const int64_t fit = ws_floats / (groups * width);
+  if (b > fit) b = fit;
+  return b;
+}
 
-// gs[n][c] += sum_p g[n][p][c] * x[n][p][c]      (caller zeroes gs)
+// gs[n][c] = sum_p g[n][p][c] * x[n][p][c]   (written, not accumulated; ws: partials workspace of >= N*C floats)
 __global__ void __launch_bounds__(256) scale_channels_gs_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ x,
-                                                                     float* __restrict__ gs, int64_t P, int C8, int64_t rows_per_block) {
+                                                                     float* __restrict__ ws, int64_t P, int C8, int64_t rows_per_block) {
   __shared__ float part[256][8];
   const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
   const int n = blockIdx.y;
@@ -89,28 +120,37 @@ __global__ void __launch_bounds__(256) scale_channels_gs_bf16_kernel(const uint4
   const uint4* gb = g + (int64_t)n * P * C8;
   const uint4* xb = x + (int64_t)n * P * C8;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = r0 + rl; r < r1; r += RL) {
+  int64_t r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {  // two independent pairs of 16-byte loads in flight
+    float a[8], b[8], a2[8], b2[8];
+    const uint4 ga = gb[r * C8 + cg], xa = xb[r * C8 + cg], gc = gb[(r + RL) * C8 + cg], xc = xb[(r + RL) * C8 + cg];
+    unpack8(ga, a), unpack8(xa, b), unpack8(gc, a2), unpack8(xc, b2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(a2[e], b2[e], fmaf(a[e], b[e], acc[e]));
+  }
+  for (; r < r1; r += RL) {
     float a[8], b[8];
     unpack8(gb[r * C8 + cg], a);
     unpack8(xb[r * C8 + cg], b);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = fmaf(a[e], b[e], acc[e]);
   }
-  chunk_reduce_atomic(acc, gs + (int64_t)n * C8 * 8, C8, part);
+  chunk_reduce_store(acc, ws + ((int64_t)n * gridDim.x + blockIdx.x) * C8 * 8, C8, part);
 }
 static bool c8_ok(int C) {
   const int c8 = C / 8;
   return C % 8 == 0 && c8 >= 1 && c8 <= 256 && (c8 & (c8 - 1)) == 0;
 }
-extern "C" int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, int N, int64_t P, int C, void* stream) {
-  if (!g || !x || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
-  if (!c8_ok(C) || !al16(g) || !al16(x)) return FMI_ERR_UNSUPPORTED;
-  int64_t blocks = ceil_div64(P, 64);
-  if (blocks > 512) blocks = 512;
+extern "C" int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, float* ws, int64_t ws_floats, int N, int64_t P,
+                                          int C, void* stream) {
+  if (!g || !x || !gs || !ws || N <= 0 || P <= 0 || C <= 0 || N > 65535 || ws_floats < (int64_t)N * C) return FMI_ERR_BAD_ARG;
+  if (!c8_ok(C) || !al16(g) || !al16(x) || !al16(ws)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = parts_for(P, N, C, ws_floats);
   const int64_t rpb = ceil_div64(P, blocks);
   blocks = ceil_div64(P, rpb);
   hipLaunchKernelGGL(scale_channels_gs_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)g,
-                     (const uint4*)x, gs, P, C / 8, rpb);
+                     (const uint4*)x, ws, P, C / 8, rpb);
+  launch_sum_parts(ws, gs, (int)blocks, C, N, (hipStream_t)stream);
   return fmi_launch_status();
 }
 
@@ -145,10 +185,11 @@ extern "C" int fmi_noise_bias_act_bf16(const uint16_t* x, const float* bias, con
   return fmi_launch_status();
 }
 
-// backward: gx = g * scale * (y > 0 ? 1 : alpha);  gbias[c] += sum_p gx;  gnw += sum gx * noise[p]   (one pass; caller zeroes both)
+// backward: gx = g * scale * (y > 0 ? 1 : alpha);  gbias[c] = sum_p gx;  gnw = sum gx * noise[p]   (one pass; both written).
+// ws: partials workspace, rows of C + 8 floats (bias sums, then the noise-weight sum), >= C + 8 floats
 __global__ void __launch_bounds__(256) noise_bias_act_bwd_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y,
                                                                       const float* __restrict__ noise, uint4* __restrict__ gx,
-                                                                      float* __restrict__ gnw, float* __restrict__ gbias, int64_t P,
+                                                                      float* __restrict__ ws, int want_nw, int64_t P,
                                                                       int C8, float alpha, float scale, int64_t rows_per_block) {
   __shared__ float part[256][8];
   __shared__ float red[4];
@@ -158,10 +199,10 @@ __global__ void __launch_bounds__(256) noise_bias_act_bwd_bf16_kernel(const uint
   if (r1 > P) r1 = P;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float an = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += RL) {
+  auto one = [&](int64_t r, const uint4& gv, const uint4& yv) {
     float a[8], b[8];
-    unpack8(g[r * C8 + cg], a);
-    unpack8(y[r * C8 + cg], b);
+    unpack8(gv, a);
+    unpack8(yv, b);
     float rs = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -171,23 +212,64 @@ __global__ void __launch_bounds__(256) noise_bias_act_bwd_bf16_kernel(const uint
     }
     if (noise) an = fmaf(rs, noise[r], an);
     gx[r * C8 + cg] = pack8(a);
+  };
+  int64_t r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {  // two independent pairs of 16-byte loads in flight
+    const uint4 g0 = g[r * C8 + cg], y0 = y[r * C8 + cg], g1 = g[(r + RL) * C8 + cg], y1 = y[(r + RL) * C8 + cg];
+    one(r, g0, y0);
+    one(r + RL, g1, y1);
   }
-  if (gbias) chunk_reduce_atomic(acc, gbias, C8, part);
-  if (noise && gnw) {
+  for (; r < r1; r += RL) one(r, g[r * C8 + cg], y[r * C8 + cg]);
+  const int W = C8 * 8 + 8;
+  chunk_reduce_store(acc, ws + (int64_t)blockIdx.x * W, C8, part);
+  if (want_nw) {
     an = block_sum_256(an, red);
-    if (threadIdx.x == 0) atomicAdd(gnw, an);
+    if (threadIdx.x == 0) ws[(int64_t)blockIdx.x * W + C8 * 8] = an;
+  }
+}
+// gbias[c] = sum of column c, gnw = sum of column C of the partial rows.  64 columns x 16 row lanes per block, 8 independent loads in
+// flight per thread (one thread per column walking 2048 rows took 0.2 ms: pure load latency)
+__global__ void __launch_bounds__(1024) nba_finish_kernel(const float* __restrict__ ws, float* __restrict__ gbias, float* __restrict__ gnw,
+                                                          int nparts, int C) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx, W = C + 8;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i <= C) {
+    int q = ty;
+    for (; q + 7 * 16 < nparts; q += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(int64_t)(q + 16 * u) * W + i];
+    }
+    for (; q < nparts; q += 16) a[0] += ws[(int64_t)q * W + i];
+  }
+  part[ty][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (ty == 0 && i <= C) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += part[l][tx];
+    if (i < C) {
+      if (gbias) gbias[i] = t;
+    } else if (gnw) {
+      gnw[0] = t;
+    }
   }
 }
 extern "C" int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, uint16_t* gx, float* gnw,
-                                           float* gbias, int64_t pixels, int C, float alpha, float scale, void* stream) {
-  if (!g || !y || !gx || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
-  if (!c8_ok(C) || !al16(g) || !al16(y) || !al16(gx)) return FMI_ERR_UNSUPPORTED;
-  int64_t blocks = ceil_div64(pixels, 64);
-  if (blocks > 2048) blocks = 2048;
+                                           float* gbias, float* ws, int64_t ws_floats, int64_t pixels, int C, float alpha, float scale,
+                                           void* stream) {
+  if (!g || !y || !gx || !ws || pixels <= 0 || C <= 0 || ws_floats < C + 8) return FMI_ERR_BAD_ARG;
+  if (!c8_ok(C) || !al16(g) || !al16(y) || !al16(gx) || !al16(ws)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = parts_for(pixels, 1, C + 8, ws_floats);
   const int64_t rpb = ceil_div64(pixels, blocks);
   blocks = ceil_div64(pixels, rpb);
+  const int want_nw = (noise && gnw) ? 1 : 0;
   hipLaunchKernelGGL(noise_bias_act_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)g,
-                     (const uint4*)y, noise, (uint4*)gx, gnw, gbias, pixels, C / 8, alpha, scale, rpb);
+                     (const uint4*)y, want_nw ? noise : nullptr, (uint4*)gx, ws, want_nw, pixels, C / 8, alpha, scale, rpb);
+  if (gbias || want_nw)
+    hipLaunchKernelGGL(nba_finish_kernel, dim3((C + 1 + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, gbias, want_nw ? gnw : nullptr,
+                       (int)blocks, C);
   return fmi_launch_status();
 }
 
@@ -311,12 +393,14 @@ __global__ void __launch_bounds__(256) torgb_fwd_bf16_kernel(const uint4* __rest
     }
   }
 }
-// backward: gx[n][p][c] = sum_o g[n][p][o] w[o][c] s[n][c];  gwm[n][o][c] += sum_p g[n][p][o] x[n][p][c];  gbias[o] += sum g
+// backward: gx[n][p][c] = sum_o g[n][p][o] w[o][c] s[n][c];  per block one partial row [3][C] of sum_p g[n][p][o] x[n][p][c] followed
+// by the three sums of g (8 floats reserved): ws[(n * blocks + b)][3 C + 8]
 __global__ void __launch_bounds__(256) torgb_bwd_bf16_kernel(const uint4* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ s, const float* __restrict__ g,
-                                                             uint4* __restrict__ gx, float* __restrict__ gwm, float* __restrict__ gbias,
+                                                             uint4* __restrict__ gx, float* __restrict__ ws,
                                                              int64_t P, int C8, int64_t rows_per_block) {
   __shared__ float part[256][8];
+  __shared__ float red[4];
   const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
   const int n = blockIdx.y, C = C8 * 8;
   float wm[3][8];
@@ -356,30 +440,39 @@ __global__ void __launch_bounds__(256) torgb_bwd_bf16_kernel(const uint4* __rest
     gxb[r * C8 + cg] = pack8(o8);
     if (cg == 0) gb[0] += g0, gb[1] += g1, gb[2] += g2;
   }
+  float* row = ws + ((int64_t)n * gridDim.x + blockIdx.x) * (3 * C + 8);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) chunk_reduce_atomic(acc[o], gwm + ((int64_t)n * 3 + o) * C, C8, part);
-  if (gbias && cg == 0) {
+  for (int o = 0; o < 3; ++o) chunk_reduce_store(acc[o], row + o * C, C8, part);
 #pragma unroll
-    for (int o = 0; o < 3; ++o) atomicAdd(gbias + o, gb[o]);
+  for (int o = 0; o < 3; ++o) {
+    const float t = block_sum_256(gb[o], red);
+    if (threadIdx.x == 0) row[3 * C + o] = t;
   }
 }
-// gw[o][c] = sum_n gwm[n][o][c] s[n][c];   gs[n][c] = sum_o gwm[n][o][c] w[o][c]
+// gwm[n][3C+8] = per-sample sums of the partial rows (sum_parts_kernel); then
+// gw[o][c] = sum_n gwm[n][o][c] s[n][c];   gs[n][c] = sum_o gwm[n][o][c] w[o][c];   gbias[o] = sum_n gwm[n][3C + o]
 __global__ void __launch_bounds__(256) torgb_finish_kernel(const float* __restrict__ gwm, const float* __restrict__ w,
                                                            const float* __restrict__ s, float* __restrict__ gw, float* __restrict__ gs,
-                                                           int N, int C) {
+                                                           float* __restrict__ gbias, int N, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  const int W = 3 * C + 8;
   if (i < 3 * C) {
     const int c = i % C, o = i / C;
     float a = 0.f;
-    for (int n = 0; n < N; ++n) a = fmaf(gwm[((int64_t)n * 3 + o) * C + c], s[(int64_t)n * C + c], a);
+    for (int n = 0; n < N; ++n) a = fmaf(gwm[(int64_t)n * W + o * C + c], s[(int64_t)n * C + c], a);
     gw[i] = a;
   }
   if (i < N * C) {
     const int c = i % C, n = i / C;
     float a = 0.f;
 #pragma unroll
-    for (int o = 0; o < 3; ++o) a = fmaf(gwm[((int64_t)n * 3 + o) * C + c], w[o * C + c], a);
+    for (int o = 0; o < 3; ++o) a = fmaf(gwm[(int64_t)n * W + o * C + c], w[o * C + c], a);
     gs[i] = a;
+  }
+  if (gbias && i < 3) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += gwm[(int64_t)n * W + 3 * C + i];
+    gbias[i] = a;
   }
 }
 static bool torgb_ok(int C) {
@@ -399,19 +492,25 @@ extern "C" int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float
                      out, P, C / 8, rpb);
   return fmi_launch_status();
 }
-/* gwm: [N][3][C] fp32 workspace, zeroed by the caller; gbias [3] zeroed (may be NULL); gw [3][C], gs [N][C] are written */
-extern "C" int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* gwm, float* gw,
-                                  float* gs, float* gbias, int N, int64_t P, int C, void* stream) {
-  if (!x || !w || !s || !g || !gx || !gwm || !gw || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
-  if (!torgb_ok(C) || !al16(x) || !al16(gx) || !al16(w) || !al16(s)) return FMI_ERR_UNSUPPORTED;
-  int64_t blocks = ceil_div64(P, 64);
-  if (blocks > 512) blocks = 512;
+/* ws: partials workspace of ws_floats >= 2 * N * (3 C + 8) floats (more = more row blocks); gw [3][C], gs [N][C], gbias [3] (may be
+ * NULL) are written, nothing has to be zeroed */
+extern "C" int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* ws,
+                                  int64_t ws_floats, float* gw, float* gs, float* gbias, int N, int64_t P, int C, void* stream) {
+  if (!x || !w || !s || !g || !gx || !ws || !gw || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  const int64_t W = 3 * (int64_t)C + 8;
+  if (ws_floats < 2 * N * W) return FMI_ERR_BAD_ARG;
+  if (!torgb_ok(C) || !al16(x) || !al16(gx) || !al16(w) || !al16(s) || !al16(ws)) return FMI_ERR_UNSUPPORTED;
+  float* gwm = ws;                 // [N][W] per-sample sums
+  float* parts = ws + N * W;       // [N][blocks][W]
+  int64_t blocks = parts_for(P, N, W, ws_floats - N * W);
   const int64_t rpb = ceil_div64(P, blocks);
   blocks = ceil_div64(P, rpb);
-  hipLaunchKernelGGL(torgb_bwd_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, w, s, g,
-                     (uint4*)gx, gwm, gbias, P, C / 8, rpb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(torgb_bwd_bf16_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, (const uint4*)x, w, s, g, (uint4*)gx, parts, P,
+                     C / 8, rpb);
+  launch_sum_parts(parts, gwm, (int)blocks, (int)W, N, st);
   const int tot = (N > 3 ? N : 3) * C;
-  hipLaunchKernelGGL(torgb_finish_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, gwm, w, s, gw, gs, N, C);
+  hipLaunchKernelGGL(torgb_finish_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, gwm, w, s, gw, gs, gbias, N, C);
   return fmi_launch_status();
 }
 #endif  // FMI_HOST_EMU

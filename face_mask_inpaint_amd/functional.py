@@ -406,6 +406,11 @@ class _ConvTranspose2dBF16(torch.autograd.Function):
         return gx, gwf, None, None, None, None, None, None
 
 
+def _parts_ws(device, floats: int) -> torch.Tensor:
+    """partials workspace of the bf16 reduction passes (contents irrelevant, fully overwritten before it is read)"""
+    return torch.empty(int(floats), device=device, dtype=torch.float32)
+
+
 class _ToRGB(torch.autograd.Function):
     """out[n,p,o] = sum_c x[n,p,c] w[o,c] s[n,c] + bias[o] + skip[n,p,o]: the 1x1 modulated convolution of ToRGB without
     demodulation (stylegan2/model.py:349-369) on bf16 activations; w [3,C], s [N,C], bias [3], skip / out [N,H,W,3] are fp32."""
@@ -427,10 +432,10 @@ class _ToRGB(torch.autograd.Function):
         g = g.contiguous()
         n, h, wd, c = x.shape
         gx = torch.empty_like(x)
-        gwm = _zeros((n, 3, c), x.device)
+        ws = _parts_ws(x.device, (2048 + n) * (3 * c + 8))
         gw, gs = torch.empty_like(w), torch.empty_like(s)
-        gb = _zeros(3, x.device) if ctx.has[0] else None
-        _L().torgb_bwd_bf16(_p(x), _p(w), _p(s), _p(g), _p(gx), _p(gwm), _p(gw), _p(gs), _p(gb), n, h * wd, c, _st())
+        gb = torch.empty(3, device=x.device, dtype=torch.float32) if ctx.has[0] else None
+        _L().torgb_bwd_bf16(_p(x), _p(w), _p(s), _p(g), _p(gx), _p(ws), ws.numel(), _p(gw), _p(gs), _p(gb), n, h * wd, c, _st())
         return gx, gw, gs, gb, (g if ctx.has[1] else None)
 
 
@@ -1098,9 +1103,13 @@ class _ScaleChannels(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             (_L().scale_channels_bf16 if b16 else _L().scale_channels_f32)(_p(g), _p(s), _p(gx), n, p, c, _st())
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and b16:
+            gs = torch.empty_like(s)
+            ws = _parts_ws(x.device, max(2048, n) * c)
+            _L().scale_channels_gs_bf16(_p(g), _p(x), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
+        elif ctx.needs_input_grad[1]:
             gs = _zeros_like(s)
-            (_L().scale_channels_gs_bf16 if b16 else _L().scale_channels_gs_f32)(_p(g), _p(x), _p(gs), n, p, c, _st())
+            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), n, p, c, _st())
         return gx, gs
 
 
@@ -1203,9 +1212,10 @@ class _NoiseBiasAct(torch.autograd.Function):
         gx = torch.empty_like(y)
         gnw = _zeros(1, y.device, torch.float32) if (has_nw and noise is not None) else None
         if y.dtype == BF16:  # one pass: gx, the bias gradient and the noise-weight gradient
-            gb = _zeros(c, y.device, torch.float32) if (has_b and ctx.needs_input_grad[1]) else None
-            _L().noise_bias_act_bwd_bf16(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), _p(gb), y.numel() // c, c,
-                                         alpha, scale, _st())
+            gb = torch.empty(c, device=y.device, dtype=torch.float32) if (has_b and ctx.needs_input_grad[1]) else None
+            ws = _parts_ws(y.device, 2048 * (c + 8))
+            _L().noise_bias_act_bwd_bf16(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), _p(gb), _p(ws), ws.numel(),
+                                         y.numel() // c, c, alpha, scale, _st())
             return gx, gb, None, gnw, None, None
         _L().noise_bias_act_bwd_f32(_p(g), _p(y), _p(noise) if gnw is not None else None, _p(gx), _p(gnw), y.numel() // c, c, alpha, scale, _st())
         gb = None

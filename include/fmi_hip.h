@@ -126,24 +126,28 @@ int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint1
 int fmi_pack_weight_bf16(const float* src_tab, uint16_t* dst_bta, int T, int A, int B, void* stream);
 /* bf16 NHWC activations around those convolutions (C % 8 == 0; per-sample / per-channel factors, noise, biases and all reduction
  * results are fp32).  Same semantics as the _f32 entries of the same names:
- *   scale_channels      y = x * s[n][c]                    (modulation / demodulation, model.py:244-252); _gs: gs[n][c] += sum_p g x
+ *   scale_channels      y = x * s[n][c]                    (modulation / demodulation, model.py:244-252); _gs: gs[n][c] = sum_p g x
  *   noise_bias_act      y = lrelu(x + bias[c] + nw*noise[p], alpha) * scale   (model.py:282-294,340-346; op/fused_act.py:72-85)
- *   noise_bias_act_bwd  gx = g*scale*(y>0 ? 1 : alpha); gbias[c] += sum gx; gnw += sum gx*noise   (ONE pass; either may be NULL)
+ *   noise_bias_act_bwd  gx = g*scale*(y>0 ? 1 : alpha); gbias[c] = sum gx; gnw = sum gx*noise   (ONE pass; either may be NULL)
+ * The reductions (_gs, _bwd, torgb_bwd) WRITE their results: each row block stores its partial sums into `ws` (ws_floats fp32, 16-byte
+ * aligned, contents irrelevant; the minimum is one partial row per sample, more lets more blocks run -- 2048 rows saturate) and a
+ * second small launch adds them: no fp32 atomics (thousands of them on a few hundred addresses serialise), bit-reproducible.
  *   upfirdn2d_nhwc      the decoder's Blur and its gradient only: up = down = 1, square FIR of 2..4 taps (model.py:52-68)
  *   torgb               out[n][p][o<3] = sum_c x w[o][c] s[n][c] + bias[o] + skip   (ToRGB, model.py:349-369; out / skip fp32)
- *   torgb_bwd           gx (bf16), gw[3][C], gs[N][C], gbias[3] (+=, may be NULL); gwm = zeroed [N][3][C] fp32 workspace */
+ *   torgb_bwd           gx (bf16), gw[3][C], gs[N][C], gbias[3] (may be NULL); ws_floats >= 2 * N * (3 C + 8) */
 int fmi_scale_channels_bf16(const uint16_t* x, const float* s, uint16_t* y, int N, int64_t P, int C, void* stream);
-int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, int N, int64_t P, int C, void* stream);
+int fmi_scale_channels_gs_bf16(const uint16_t* g, const uint16_t* x, float* gs, float* ws, int64_t ws_floats, int N, int64_t P, int C,
+                               void* stream);
 int fmi_noise_bias_act_bf16(const uint16_t* x, const float* bias, const float* noise, const float* nw, uint16_t* y, int64_t pixels, int C,
                             float alpha, float scale, void* stream);
 int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, uint16_t* gx, float* gnw, float* gbias,
-                                int64_t pixels, int C, float alpha, float scale, void* stream);
+                                float* ws, int64_t ws_floats, int64_t pixels, int C, float alpha, float scale, void* stream);
 int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh, int kw,
                             int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float* s, const float* bias, const float* skip, float* out, int N,
                        int64_t P, int C, void* stream);
-int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* gwm, float* gw, float* gs,
-                       float* gbias, int N, int64_t P, int C, void* stream);
+int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* ws, int64_t ws_floats,
+                       float* gw, float* gs, float* gbias, int N, int64_t P, int C, void* stream);
 
 /* dbias[k] = sum over rows of g[rows, cstride] (caller zeroes dbias). */
 int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstride, float* dbias, void* stream);
