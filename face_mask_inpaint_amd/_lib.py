@@ -45,8 +45,8 @@ SIGNATURES = {
     "fmi_conv2d_thin_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_input_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_wgrad_f32": [PD, vp, vp, vp, vp, vp],
-    "fmi_conv2d_fwd_bf16": [PD, vp, vp, vp, vp, vp],
-    "fmi_conv2d_dgrad_bf16": [PD, vp, vp, vp, vp, vp],
+    "fmi_conv2d_fwd_bf16": [PD, vp, vp, vp, vp, vp, i64, vp],
+    "fmi_conv2d_dgrad_bf16": [PD, vp, vp, vp, vp, vp, i64, vp],
     "fmi_conv2d_wgrad_bf16": [PD, vp, vp, vp, vp],
     "fmi_pack_weight_bf16": [vp, vp, i32, i32, i32, vp],
     "fmi_scale_channels_bf16": [vp, vp, vp, i32, i64, i32, vp],

@@ -127,9 +127,29 @@ using TB64x64 = TileB<2, 2, 1, 1>;
 using TB64x128 = TileB<2, 2, 1, 2>;
 using TB256x256 = TileB<2, 4, 4, 2>;  // 8 waves, 128 x 64 per wave: 128 FLOP per staged byte (the 128 x 128 tile: 64 -> L2-rate bound)
 
+// One launch = up to four "phases" (the sub-pixel phases of a strided adjoint, i.e. of a ConvTranspose2d forward; one phase
+// otherwise) x an optional split of the reduction: grid = (tiles of the largest phase, phases, splits).
+struct ConvPhaseB {
+  ConvKB la;
+  ConvWKB lb;
+  ConvEpB ep;
+  int M, K, tiles;
+};
+struct ConvSetB {
+  ConvPhaseB ph[4];
+  int N, tiles_n, ksplit;
+  float* ws;  // split reduction: fp32 twin of the output (zeroed by the caller), partial sums meet through atomics
+};
+
 template <class T, int BK, int NST = 2>
-__global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb, ConvEpB ep, int M, int N, int K, int tiles_n) {
+__global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvSetB set) {
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  if (lid >= set.ph[blockIdx.y].tiles) return;  // whole workgroup
+  const ConvKB la = set.ph[blockIdx.y].la;
+  const ConvWKB lb = set.ph[blockIdx.y].lb;
+  const ConvEpB ep = set.ph[blockIdx.y].ep;
+  const int M = set.ph[blockIdx.y].M, K = set.ph[blockIdx.y].K, N = set.N, tiles_n = set.tiles_n;
   constexpr int CPR = BK / 8;            // 16-byte chunks per image row
   constexpr int NLA = (BM * CPR + NT - 1) / NT, NLB = (BN * CPR + NT - 1) / NT;
   constexpr int STAGE = (BM + BN) * BK;  // bf16 elements
@@ -138,7 +158,6 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb,
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
@@ -240,11 +259,14 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb,
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
-  const int nt = (K + BK - 1) / BK;
+  const int nt_all = (K + BK - 1) / BK, per = (nt_all + set.ksplit - 1) / set.ksplit;
+  const int kt0 = blockIdx.z * per;
+  const int nt = (kt0 + per <= nt_all ? per : nt_all - kt0);  // reduction tiles of this split (may be <= 0)
+  if (nt <= 0) return;
   const int nw = (BM * CPR % NT == 0 && BN * CPR % NT == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
 #pragma unroll
   for (int p = 0; p < DEPTH; ++p)
-    if (p < nt) issue(p * BK, p);
+    if (p < nt) issue((kt0 + p) * BK, p);
   int st = 0, stn = DEPTH;
   for (int t = 0; t < nt; ++t) {
     int pend = nt - 1 - t;  // tile t must have landed; up to DEPTH-1 newer tiles may stay in flight
@@ -252,7 +274,7 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb,
     wait_copies(pend * nw);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + DEPTH < nt) issue((t + DEPTH) * BK, stn);
+    if (t + DEPTH < nt) issue((kt0 + t + DEPTH) * BK, stn);
     compute(st);
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
@@ -273,6 +295,12 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb,
         quad_transpose(a, c);
         const int col = n0 + wn + j * 32 + colq;
         if (row >= M || col >= N) continue;
+        if (set.ws) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N) atomicAdd(set.ws + off + col + e, a[e]);
+          continue;
+        }
         if (ep.colscale) {
           const float* cs = ep.colscale + (int64_t)n_s * ep.Nout + col;
 #pragma unroll
@@ -294,15 +322,52 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvKB la, ConvWKB lb,
   }
 }
 
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    uint2 o;
+    o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    reinterpret_cast<uint2*>(dst)[i] = o;
+  }
+}
+
+// phases: nph filled entries of set.ph (la, lb, ep, M, K); N = output channels.  ws (may be null): zeroed fp32 twin of the output
+// tensor with out_elems elements -- small feature maps with a deep reduction (the 4^2 .. 16^2 layers: 2 - 32 output tiles) then
+// split the reduction over workgroups and the sums are converted to bf16 by a second launch.
 template <int BK>
-static int launch_conv_bf16(const ConvKB& la, const ConvWKB& lb, const ConvEpB& ep, int M, int N, int K, hipStream_t st) {
+static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws, int64_t ws_floats, int64_t out_elems, hipStream_t st) {
+  int Mmax = 0, Kmax = 0;
+  for (int p = 0; p < nph; ++p) {
+    if (set.ph[p].M > Mmax) Mmax = set.ph[p].M;
+    if (set.ph[p].K > Kmax) Kmax = set.ph[p].K;
+  }
+  set.N = N;
+  const bool can_split = ws && ws_floats >= out_elems && out_elems % 4 == 0 && !set.ph[0].ep.colscale;
 #define FMI_LAUNCH_B(TILE)                                                                                                        \
   do {                                                                                                                            \
-    const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                                     \
-    if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                       \
-    hipLaunchKernelGGL((conv_bf16_kernel<TILE, BK>), dim3((unsigned)(tm * tn)), dim3(TILE::NT), 0, st, la, lb, ep, M, N, K, (int)tn); \
+    const int64_t tn = ceil_div64(N, TILE::BN);                                                                                   \
+    int64_t tmax = 0, tsum = 0;                                                                                                   \
+    for (int p = 0; p < nph; ++p) {                                                                                               \
+      const int64_t t = ceil_div64(set.ph[p].M, TILE::BM) * tn;                                                                   \
+      if (t > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                           \
+      set.ph[p].tiles = (int)t;                                                                                                   \
+      tsum += t;                                                                                                                  \
+      if (t > tmax) tmax = t;                                                                                                     \
+    }                                                                                                                             \
+    int64_t ks = 1;                                                                                                               \
+    if (can_split && tsum < 128 && Kmax >= 1024) {                                                                                \
+      ks = ceil_div64(256, tsum);                                                                                                 \
+      if (ks > Kmax / 256) ks = Kmax / 256;                                                                                       \
+    }                                                                                                                             \
+    set.tiles_n = (int)tn;                                                                                                        \
+    set.ksplit = (int)ks;                                                                                                         \
+    set.ws = ks > 1 ? ws : nullptr;                                                                                               \
+    hipLaunchKernelGGL((conv_bf16_kernel<TILE, BK>), dim3((unsigned)tmax, nph, (unsigned)ks), dim3(TILE::NT), 0, st, set);        \
+    if (ks > 1)                                                                                                                   \
+      hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(fmi_bw_grid(out_elems / 4, 256)), dim3(256), 0, st, ws, y, out_elems / 4);      \
   } while (0)
-  auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn); };
+  auto wgs = [&](int bm, int bn) { return ceil_div64(Mmax, bm) * ceil_div64(N, bn) * nph; };
   static const int tile_dbg = getenv("FMI_BF16_TILE") ? atoi(getenv("FMI_BF16_TILE")) : 0;  // debug: 1 = never use the 8-wave tiles
   if (N <= 32) {
     FMI_LAUNCH_B(TB128x32);
@@ -341,7 +406,7 @@ extern "C" int fmi_conv2d_bf16_supported(const fmi_conv_desc* d) {
 }
 
 extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y,
-                                   void* stream) {
+                                   float* ws, int64_t ws_floats, void* stream) {
   int rc = check_desc_b(d);
   if (rc) return rc;
   if (!x || !wnk || !y) return FMI_ERR_BAD_ARG;
@@ -354,22 +419,30 @@ extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, co
   g.pad_mode = 0; g.vec = 1;
   g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
   g.img_bs = 0;
-  ConvKB la{x, g};
-  ConvWKB lb{wnk, g, d->K, d->kh * d->kw};
-  ConvEpB ep{y, colscale, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, d->K, g.dGW, g.dG,
-             (d->K % 4 == 0 && d->y_cstride % 4 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0};
-  if (d->C % 64 == 0) return launch_conv_bf16<64>(la, lb, ep, g.Mdim(), d->K, g.Kdim(), (hipStream_t)stream);
-  return launch_conv_bf16<32>(la, lb, ep, g.Mdim(), d->K, g.Kdim(), (hipStream_t)stream);
+  ConvSetB set{};
+  set.ph[0].la = ConvKB{x, g};
+  set.ph[0].lb = ConvWKB{wnk, g, d->K, d->kh * d->kw};
+  set.ph[0].ep = ConvEpB{y, colscale, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, d->K, g.dGW, g.dG,
+                         (d->K % 4 == 0 && d->y_cstride % 4 == 0 && ((uintptr_t)y & 7) == 0) ? 1 : 0};
+  set.ph[0].M = g.Mdim();
+  set.ph[0].K = g.Kdim();
+  const int64_t out_elems = (int64_t)d->N * d->OH * d->OW * d->y_cstride;
+  if (ws && (((uintptr_t)ws & 15) || ((uintptr_t)y & 7))) ws = nullptr;
+  if (d->C % 64 == 0) return launch_conv_bf16<64>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream);
+  return launch_conv_bf16<32>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream);
 }
 
 /* dx = adjoint of the convolution described by d applied to dy; wck = weights packed [C][kh*kw][K] */
 extern "C" int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx,
-                                     void* stream) {
+                                     float* ws, int64_t ws_floats, void* stream) {
   int rc = check_desc_b(d);
   if (rc) return rc;
   if (!dy || !wck || !dx) return FMI_ERR_BAD_ARG;
   if (d->K % 32 != 0 || d->y_cstride % 8 != 0 || !aligned16b(dy) || !aligned16b(wck)) return FMI_ERR_UNSUPPORTED;
   const int s = d->stride;
+  if (s > 2) return FMI_ERR_UNSUPPORTED;  // at most four sub-pixel phases per launch
+  ConvSetB set{};
+  int nph = 0;
   for (int py = 0; py < s; ++py) {
     for (int px = 0; px < s; ++px) {
       const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
@@ -387,16 +460,20 @@ extern "C" int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy,
       g.dntx = make_fastdiv(g.ntx > 0 ? g.ntx : 1);
       g.img_bs = 0;
       if (g.nty == 0 || g.ntx == 0) { g.nty = 0; g.ntx = 1; }
-      ConvKB la{dy, g};
-      ConvWKB lb{wck, g, d->C, d->kh * d->kw};
-      ConvEpB ep{dx, colscale, GH, GW, s, py, px, d->H, d->W, d->x_cstride, d->C, g.dGW, g.dG,
-                 (d->C % 4 == 0 && d->x_cstride % 4 == 0 && ((uintptr_t)dx & 7) == 0) ? 1 : 0};
-      rc = d->K % 64 == 0 ? launch_conv_bf16<64>(la, lb, ep, g.Mdim(), d->C, g.Kdim(), (hipStream_t)stream)
-                          : launch_conv_bf16<32>(la, lb, ep, g.Mdim(), d->C, g.Kdim(), (hipStream_t)stream);
-      if (rc) return rc;
+      ConvPhaseB& P = set.ph[nph++];
+      P.la = ConvKB{dy, g};
+      P.lb = ConvWKB{wck, g, d->C, d->kh * d->kw};
+      P.ep = ConvEpB{dx, colscale, GH, GW, s, py, px, d->H, d->W, d->x_cstride, d->C, g.dGW, g.dG,
+                     (d->C % 4 == 0 && d->x_cstride % 4 == 0 && ((uintptr_t)dx & 7) == 0) ? 1 : 0};
+      P.M = g.Mdim();
+      P.K = g.Kdim();
     }
   }
-  return FMI_OK;
+  if (nph == 0) return FMI_OK;
+  const int64_t out_elems = (int64_t)d->N * d->H * d->W * d->x_cstride;
+  if (ws && (((uintptr_t)ws & 15) || ((uintptr_t)dx & 7))) ws = nullptr;
+  return d->K % 64 == 0 ? launch_conv_bf16<64>(set, nph, d->C, dx, ws, ws_floats, out_elems, (hipStream_t)stream)
+                        : launch_conv_bf16<32>(set, nph, d->C, dx, ws, ws_floats, out_elems, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

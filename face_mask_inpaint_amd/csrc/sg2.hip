@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_fir_kernel(const float* __
   }
 }
 
+// column-run FIR shared with the bf16 path (sg2_bf16.hip); returns 0 when it does not apply
+extern "C" int fmi_internal_fir_run_launch(const void* in, const float* kernel, void* out, int N, int in_h, int in_w, int CV, int out_h,
+                                           int out_w, int k, int pad_x0, int pad_y0, int bf16, void* stream);
 extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int N, int in_h, int in_w, int C,
                                       int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                                       int pad_y0, int pad_y1, void* stream) {
@@ -196,6 +199,7 @@ extern "C" int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, floa
   const int64_t total = (int64_t)N * out_h * out_w * C;
   if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && C % 4 == 0 && kh == kw && (kh == 4 || kh == 3 || kh == 2) &&
       (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    if (fmi_internal_fir_run_launch(in, kernel, out, N, in_h, in_w, C / 4, out_h, out_w, kh, pad_x0, pad_y0, 0, stream)) return fmi_launch_status();
     const int64_t tv = (int64_t)N * out_h * ((out_w + 1) / 2) * (C / 4);
     if (tv < (1ll << 31) && (int64_t)N * in_h * in_w * C < (1ll << 40)) {
       const int grid = fmi_bw_grid(tv, 256);

@@ -6,6 +6,7 @@
 //   upfirdn2d_nhwc      Blur after the up-convolutions    (model.py:52-68, op/upfirdn2d.py:85-147)
 //   torgb               1x1 modulated conv C -> 3 without demodulation + bias + skip (model.py:349-369)
 #include "common.h"
+#include <cstdlib>
 
 #ifndef FMI_HOST_EMU
 typedef uint16_t bf16_t;
@@ -326,6 +327,110 @@ __global__ void __launch_bounds__(256) upfirdn2d_nhwc_fir_bf16_kernel(const uint
     if (ox + 1 < out_w) o[C8] = pack8(a1);
   }
 }
+// Column-run form of the same FIR, bf16 (E = 8 channels per 16 bytes) and fp32 (E = 4): one thread = (2 adjacent output columns,
+// R consecutive output rows, E channels).  Every input row of the run is read ONCE as KW+1 16-byte loads and feeds up to KH output
+// rows: (R + KH - 1)(KW + 1) loads for 2R outputs -- 4.4 per output at R = 4 against 10 for the per-pixel-pair form, which was bound
+// by load issue, not by HBM (bf16 moved half the bytes in the same time as fp32).
+template <int KH, int KW, int R, bool BF>
+__global__ void __launch_bounds__(256) upfirdn2d_nhwc_fir_run_kernel(const uint4* __restrict__ in, const float* __restrict__ kernel,
+                                                                     uint4* __restrict__ out, int in_h, int in_w, int CV, int out_h,
+                                                                     int out_w, int pad_x0, int pad_y0, int total) {
+  constexpr int E = BF ? 8 : 4;
+  float kf[KH][KW];
+#pragma unroll
+  for (int a = 0; a < KH; ++a)
+#pragma unroll
+    for (int b = 0; b < KW; ++b) kf[a][b] = kernel[(KH - 1 - a) * KW + (KW - 1 - b)];
+  const int pw = (out_w + 1) >> 1, ph = (out_h + R - 1) / R;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int cv = i % CV;
+    int r = i / CV;
+    const int px = r % pw;
+    r /= pw;
+    const int ry = r % ph, n = r / ph;
+    const int ox = 2 * px, oy0 = ry * R;
+    const int iy0 = oy0 - pad_y0, ix0 = ox - pad_x0;
+    float acc[R][2][E];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[q][0][e] = 0.f, acc[q][1][e] = 0.f;
+    const uint4* base = in + (int64_t)n * in_h * in_w * CV + cv;
+#pragma unroll
+    for (int t = 0; t < R + KH - 1; ++t) {
+      const int iy = iy0 + t;
+      if ((unsigned)iy >= (unsigned)in_h) continue;
+      const uint4* row = base + (int64_t)iy * in_w * CV;
+      float v[KW + 1][E];
+#pragma unroll
+      for (int b = 0; b <= KW; ++b) {
+        const int ix = ix0 + b;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)ix < (unsigned)in_w) raw = row[(int64_t)ix * CV];
+        if constexpr (BF) {
+          unpack8(raw, v[b]);
+        } else {
+          v[b][0] = __uint_as_float(raw.x), v[b][1] = __uint_as_float(raw.y), v[b][2] = __uint_as_float(raw.z), v[b][3] = __uint_as_float(raw.w);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int a = t - q;  // tap row of this input row for output row q (compile-time after unrolling)
+        if (a < 0 || a >= KH) continue;
+#pragma unroll
+        for (int b = 0; b < KW; ++b) {
+          const float k0 = kf[a][b];
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            acc[q][0][e] = fmaf(v[b][e], k0, acc[q][0][e]);
+            acc[q][1][e] = fmaf(v[b + 1][e], k0, acc[q][1][e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int oy = oy0 + q;
+      if (oy >= out_h) break;
+      uint4* o = out + ((int64_t)(n * out_h + oy) * out_w + ox) * CV + cv;
+      if constexpr (BF) {
+        o[0] = pack8(acc[q][0]);
+        if (ox + 1 < out_w) o[CV] = pack8(acc[q][1]);
+      } else {
+        o[0] = make_uint4(__float_as_uint(acc[q][0][0]), __float_as_uint(acc[q][0][1]), __float_as_uint(acc[q][0][2]), __float_as_uint(acc[q][0][3]));
+        if (ox + 1 < out_w)
+          o[CV] = make_uint4(__float_as_uint(acc[q][1][0]), __float_as_uint(acc[q][1][1]), __float_as_uint(acc[q][1][2]), __float_as_uint(acc[q][1][3]));
+      }
+    }
+  }
+}
+// shared launcher (also called by the fp32 entry in sg2.hip): CV = channels / E vectors per pixel; returns false if it does not apply
+extern "C" int fmi_internal_fir_run_launch(const void* in, const float* kernel, void* out, int N, int in_h, int in_w, int CV, int out_h,
+                                           int out_w, int k, int pad_x0, int pad_y0, int bf16, void* stream) {
+  // rows per thread, measured (GB/s of in + out at the decoder's Blur shapes): fp32 R = 8: 4.0-4.9 TB/s (R = 4: 3.5-4.3); bf16 R = 4: 3.7-4.2
+  // (R = 8: 3.4-3.9, 128 accumulators cost occupancy); the per-pixel-pair form: 2.4 / 1.9-2.4
+  const int R = bf16 ? 4 : 8;
+  const int64_t tv = (int64_t)N * ((out_h + R - 1) / R) * ((out_w + 1) / 2) * CV;
+  if (tv >= (1ll << 31) || out_h < 2 * R) return 0;
+  static const bool off = getenv("FMI_FIR_RUN_OFF") != nullptr;
+  if (off) return 0;
+  const int grid = fmi_bw_grid(tv, 256);
+  hipStream_t st = (hipStream_t)stream;
+#define RUN_LAUNCH(K_, BF_)                                                                                                          \
+  hipLaunchKernelGGL((upfirdn2d_nhwc_fir_run_kernel<K_, K_, (BF_ ? 4 : 8), BF_>), dim3(grid), dim3(256), 0, st, (const uint4*)in, kernel, \
+                     (uint4*)out, in_h, in_w, CV, out_h, out_w, pad_x0, pad_y0, (int)tv)
+  if (bf16) {
+    if (k == 4) RUN_LAUNCH(4, true);
+    else if (k == 3) RUN_LAUNCH(3, true);
+    else RUN_LAUNCH(2, true);
+  } else {
+    if (k == 4) RUN_LAUNCH(4, false);
+    else if (k == 3) RUN_LAUNCH(3, false);
+    else RUN_LAUNCH(2, false);
+  }
+#undef RUN_LAUNCH
+  return 1;
+}
 extern "C" int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh,
                                        int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                        void* stream) {
@@ -335,6 +440,7 @@ extern "C" int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, 
   const int fh = in_h + pad_y0 + pad_y1 - kh, fw = in_w + pad_x0 + pad_x1 - kw;
   if (fh < 0 || fw < 0) return FMI_ERR_BAD_ARG;
   const int out_h = fh + 1, out_w = fw + 1;
+  if (fmi_internal_fir_run_launch(in, kernel, out, N, in_h, in_w, C / 8, out_h, out_w, kh, pad_x0, pad_y0, 1, stream)) return fmi_launch_status();
   const int64_t tv = (int64_t)N * out_h * ((out_w + 1) / 2) * (C / 8);
   if (tv >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
   const int grid = fmi_bw_grid(tv, 256);

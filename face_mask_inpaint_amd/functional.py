@@ -315,6 +315,15 @@ def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_m
 BF16 = torch.bfloat16
 
 
+def _split_ws(out: torch.Tensor, kred: int):
+    """zeroed fp32 twin of a SMALL bf16 convolution output with a deep reduction (the 4^2 .. 16^2 decoder layers): lets the library
+    split the reduction over workgroups; None (= never split) otherwise"""
+    if out.numel() > (1 << 22) or kred < 1024:
+        return None, 0
+    ws = torch.zeros(out.numel(), device=out.device, dtype=torch.float32)
+    return ws, ws.numel()
+
+
 def _pack_bf16(src_tab: torch.Tensor) -> torch.Tensor:
     """fp32 [T][A][B] -> bf16 [B][T][A] (reduction index contiguous): wf -> [K][taps][C], wt -> [C][taps][K]"""
     t, a, b = src_tab.shape
@@ -335,8 +344,10 @@ class _Conv2dBF16(torch.autograd.Function):
         k = wf.shape[2]
         d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=BF16)
+        wnk = _pack_bf16(wf)
+        ws, wsn = _split_ws(y, c * kh * kw)
         with _prof(f"conv_fwd_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * n * oh * ow * k * c * kh * kw):
-            lib.conv2d_fwd_bf16(C.byref(d), _p(x), _p(_pack_bf16(wf)), None, _p(y), _st())
+            lib.conv2d_fwd_bf16(C.byref(d), _p(x), _p(wnk), None, _p(y), _p(ws), wsn, _st())
         ctx.save_for_backward(x, wf, wt)
         ctx.cfg = (kh, kw, stride, pad)
         return y
@@ -353,8 +364,10 @@ class _Conv2dBF16(torch.autograd.Function):
         gx = gwf = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            wck = _pack_bf16(wt)
+            ws, wsn = _split_ws(gx, k * kh * kw)
             with _prof(f"conv_dgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
-                lib.conv2d_dgrad_bf16(C.byref(d), _p(gy), _p(_pack_bf16(wt)), None, _p(gx), _st())
+                lib.conv2d_dgrad_bf16(C.byref(d), _p(gy), _p(wck), None, _p(gx), _p(ws), wsn, _st())
         if ctx.needs_input_grad[1]:
             gwf = _zeros_like(wf)
             with _prof(f"conv_wgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
@@ -378,8 +391,10 @@ class _ConvTranspose2dBF16(torch.autograd.Function):
         if (oh, ow) != (h, w):
             raise FmiError("unsupported ConvTranspose2d geometry")
         y = torch.empty((n, H, W, cb), device=x.device, dtype=BF16)
+        wck = _pack_bf16(wt)
+        ws, wsn = _split_ws(y, cs * kh * kw // (stride * stride))
         with _prof(f"convT_fwd_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
-            lib.conv2d_dgrad_bf16(C.byref(d), _p(x), _p(_pack_bf16(wt)), None, _p(y), _st())
+            lib.conv2d_dgrad_bf16(C.byref(d), _p(x), _p(wck), None, _p(y), _p(ws), wsn, _st())
         ctx.save_for_backward(x, wf)
         ctx.cfg, ctx.HW = (kh, kw, stride, pad), (H, W)
         return y
@@ -397,8 +412,10 @@ class _ConvTranspose2dBF16(torch.autograd.Function):
         gx = gwf = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            wnk = _pack_bf16(wf)
+            ws, wsn = _split_ws(gx, cb * kh * kw)
             with _prof(f"convT_dgrad_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
-                lib.conv2d_fwd_bf16(C.byref(d), _p(gy), _p(_pack_bf16(wf)), None, _p(gx), _st())
+                lib.conv2d_fwd_bf16(C.byref(d), _p(gy), _p(wnk), None, _p(gx), _p(ws), wsn, _st())
         if ctx.needs_input_grad[1]:
             gwf = _zeros_like(wf)
             with _prof(f"convT_wgrad_bf16|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):

@@ -113,11 +113,16 @@ int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
  * Needs the reduced channel count % 32 == 0, pixel pitches % 8 == 0, 16-byte aligned bases and zero padding
  * (fmi_conv2d_bf16_supported); anything else returns FMI_ERR_UNSUPPORTED -- there is no silent fp32 detour.
  * colscale (may be NULL): [N][out channels] fp32, multiplied into the result per (sample, channel) -- the demodulation factor.
- * The adjoint handles stride > 1 by sub-pixel phases, i.e. it is also the ConvTranspose2d forward of the upsampling layers.
+ * The adjoint handles stride 2 by sub-pixel phases, i.e. it is also the ConvTranspose2d forward of the upsampling layers.
+ * ws (may be NULL): a ZEROED fp32 buffer of ws_floats >= elements of the output tensor; when given (and colscale is NULL) small
+ * feature maps with a deep reduction split it over workgroups (fp32 atomics into ws, then one conversion launch).  All sub-pixel
+ * phases of a stride-2 adjoint run in ONE launch; stride > 2 is FMI_ERR_UNSUPPORTED.
  * ---------------------------------------------------------------------- */
 int fmi_conv2d_bf16_supported(const fmi_conv_desc* d);
-int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y, void* stream);
-int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx, void* stream);
+int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y, float* ws,
+                        int64_t ws_floats, void* stream);
+int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx, float* ws,
+                          int64_t ws_floats, void* stream);
 /* dwf[tap][C][K] (fp32, the layout of fmi_conv2d_wgrad_f32) += sum over pixels x (gathered) * dy; fp32 atomics across the pixel
  * splits, caller zeroes dwf.  Operands reach the matrix cores through ds_read_b64_tr_b16 (the reduction index -- pixels -- is the
  * slow index of both NHWC tensors).  Needs C % 32 == 0, K % 8 == 0. */

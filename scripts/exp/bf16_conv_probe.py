@@ -33,13 +33,13 @@ def run(n, c, k, h, w, ks, stride, pad, colscale=False):
     gh = gy.permute(0, 2, 3, 1).contiguous().to(dev)
     cs = (torch.rand(n, k, generator=g) + 0.5).to(dev) if colscale else None
     y = torch.full((n, oh, ow, k), float("nan"), dtype=torch.bfloat16, device=dev)
-    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), st)
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), None, 0, st)
     yr = y_ref.permute(0, 2, 3, 1)
     if colscale:
         yr = yr * cs.cpu().view(n, 1, 1, k)
     e1 = (y.float().cpu() - yr).abs().max().item() / yr.abs().max().item()
     dx = torch.full((n, h, w, c), float("nan"), dtype=torch.bfloat16, device=dev)
-    lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), st)
+    lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), None, 0, st)
     dr = dx_ref.permute(0, 2, 3, 1)
     e2 = (dx.float().cpu() - dr).abs().max().item() / dr.abs().max().item()
     dwf = torch.zeros(ks * ks, c, k, device=dev)
@@ -47,8 +47,8 @@ def run(n, c, k, h, w, ks, stride, pad, colscale=False):
     e3 = (dwf.cpu() - dw_ref).abs().max().item() / dw_ref.abs().max().item()
     torch.cuda.synchronize()
     t = []
-    for fn in (lambda: lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), st),
-               lambda: lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), st),
+    for fn in (lambda: lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), None, 0, st),
+               lambda: lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), None, 0, st),
                lambda: lib.conv2d_wgrad_bf16(C.byref(d), FF._p(xh), FF._p(gh), FF._p(dwf), st)):
         for _ in range(3):
             fn()

@@ -15,8 +15,8 @@ for (n, c, k, h) in [(16, 512, 512, 64), (16, 256, 256, 128), (16, 128, 128, 256
     dwf = torch.zeros(9, c, k, device=dev)
     st = FF._st()
     res = []
-    for fn in (lambda: lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(wnk), None, FF._p(y), st),
-               lambda: lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gy), FF._p(wck), None, FF._p(dx), st),
+    for fn in (lambda: lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(wnk), None, FF._p(y), None, 0, st),
+               lambda: lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gy), FF._p(wck), None, FF._p(dx), None, 0, st),
                lambda: lib.conv2d_wgrad_bf16(C.byref(d), FF._p(x), FF._p(gy), FF._p(dwf), st)):
         for _ in range(5):
             fn()

@@ -65,18 +65,48 @@ def test_conv_bf16_entries(dev, FF, n, c, k, h, w, ks, stride, pad):
     st = FF._st()
     cs = (torch.rand(n, k, generator=g) + 0.5).to(dev)
     y = torch.full((n, oh, ow, k), float("nan"), dtype=BF, device=dev)
-    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), st)
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), None, 0, st)
     close_bf16(y, y_ref.detach().permute(0, 2, 3, 1))
-    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), st)
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), None, 0, st)
     close_bf16(y, y_ref.detach().permute(0, 2, 3, 1) * cs.cpu().view(n, 1, 1, k))
     if k % 32 == 0:
         dx = torch.full((n, h, w, c), float("nan"), dtype=BF, device=dev)
-        lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), st)
+        lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), None, 0, st)
         close_bf16(dx, xr.grad.permute(0, 2, 3, 1))
     dwf = torch.zeros(ks * ks, c, k, device=dev)
     lib.conv2d_wgrad_bf16(C.byref(d), FF._p(xh), FF._p(gh), FF._p(dwf), st)
     ref = wr.grad.permute(2, 3, 1, 0).reshape(ks * ks, c, k)
     torch.testing.assert_close(dwf.cpu(), ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item() * (n * oh * ow) ** 0.5)
+
+
+@pytest.mark.parametrize("n,c,k,h,stride", [(2, 256, 128, 8, 1), (16, 512, 512, 4, 1), (2, 128, 256, 9, 2), (1, 512, 64, 6, 1)])
+def test_conv_bf16_split_reduction(dev, FF, n, c, k, h, stride):
+    """small feature maps with a deep reduction: with a zeroed fp32 workspace the library splits the reduction over workgroups
+    (fp32 atomics + one conversion launch); all four sub-pixel phases of a stride-2 adjoint share that launch"""
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(c + k + h)
+    pad = 1 if stride == 1 else 0
+    x = bf(torch.randn(n, c, h, h, generator=g))
+    wt_ = bf(torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5)
+    xr = x.float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt_.float(), stride=stride, padding=pad)
+    gy = bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy.float())
+    d, oh, ow = FF.conv_desc(n, h, h, c, k, 3, 3, stride, pad, 0)
+    wnk = FF._pack_bf16(wt_.float().permute(2, 3, 1, 0).reshape(9, c, k).contiguous().to(dev))
+    wck = FF._pack_bf16(wt_.float().permute(2, 3, 0, 1).reshape(9, k, c).contiguous().to(dev))
+    xh, gh = x.permute(0, 2, 3, 1).contiguous().to(dev), gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    st = FF._st()
+    y = torch.full((n, oh, ow, k), float("nan"), dtype=BF, device=dev)
+    ws = torch.zeros(y.numel(), device=dev)
+    lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), FF._p(ws), ws.numel(), st)
+    close_bf16(y, y_ref.detach().permute(0, 2, 3, 1))
+    dx = torch.full((n, h, h, c), float("nan"), dtype=BF, device=dev)
+    ws = torch.zeros(dx.numel(), device=dev)
+    lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), FF._p(ws), ws.numel(), st)
+    close_bf16(dx, xr.grad.permute(0, 2, 3, 1))
 
 
 def test_conv_bf16_rejects_unsupported(dev, FF):
@@ -89,7 +119,7 @@ def test_conv_bf16_rejects_unsupported(dev, FF):
     w = torch.zeros(32, 9, 24, dtype=BF, device=dev)
     y = torch.zeros(1, 8, 8, 32, dtype=BF, device=dev)
     with pytest.raises(_lib.FmiError, match="unsupported"):
-        lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(w), None, FF._p(y), FF._st())
+        lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(w), None, FF._p(y), None, 0, FF._st())
 
 
 @pytest.mark.parametrize("n,h,w,c", [(2, 9, 7, 64), (3, 16, 16, 512), (1, 5, 6, 32)])
