@@ -10,6 +10,7 @@
 //  * any up / down / kernel size is accepted (the reference's CUDA kernel returns uninitialised memory
 //    outside six hard-coded modes, op/upfirdn2d_kernel.cu:172-268).
 #include "common.h"
+#include <cstdlib>
 
 #define UF_TH 16
 #define UF_TW 64
@@ -154,6 +155,118 @@ __global__ void __launch_bounds__(256) upfirdn2d_fir_kernel(const T* __restrict_
   }
 }
 
+// Wide FIR path (output rows of a multiple of 4 elements, 16- / 8-byte aligned): 32 x 128 output tile, a thread owns 4 adjacent
+// columns x 4 rows.  The scalar form above issues one 4-byte (bf16: 2-byte) load AND store per output element and is bound by
+// those instructions -- bf16 took exactly the time of fp32.  Here the window is staged with 16-byte loads (4 fp32 / 8 bf16; the
+// addresses are only element- resp. word-aligned: the Blur input is 1025 wide), every staged row is read once for up to KH output
+// rows (3 LDS reads per output) and every output row piece leaves as one 16-byte (bf16: 8-byte) store.
+#define FW_TH 32
+#define FW_TW 128
+struct __attribute__((packed, aligned(4))) uf_f4 {
+  float v[4];
+};
+struct __attribute__((packed, aligned(4))) uf_h8 {
+  uint32_t w[4];
+};
+template <class T, int KH, int KW>
+__global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict__ in, const T* __restrict__ kernel, T* __restrict__ out,
+                                                             UfParams p) {
+  constexpr int IH = FW_TH + KH - 1, IW = FW_TW + KW - 1, LDW = IW + 2;
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int EV = BF ? 8 : 4;  // elements per 16-byte load
+  __shared__ float sx[IH * LDW];
+  float kf[KH][KW];
+#pragma unroll
+  for (int a = 0; a < KH; ++a)
+#pragma unroll
+    for (int b = 0; b < KW; ++b) kf[a][b] = uf_ld(kernel, (KH - 1 - a) * KW + (KW - 1 - b));
+  const int tid = threadIdx.x;
+  int b_ = blockIdx.x;
+  const int tx = b_ % p.tiles_x;
+  b_ /= p.tiles_x;
+  const int ty = b_ % p.tiles_y;
+  const int plane = b_ / p.tiles_y;
+  const int oy0 = ty * FW_TH, ox0 = tx * FW_TW;
+  const int iy0 = oy0 - p.pad_y0, ix0 = ox0 - p.pad_x0;
+  const int64_t pbase = (int64_t)plane * p.in_h * p.in_w;  // element index of the plane
+  const int64_t pend = (int64_t)p.major * p.in_h * p.in_w; // one past the last element of the tensor
+  // staging: row ry of the window = elements [rowE, rowE + IW) of the flat tensor (where inside the image); vector j of that row
+  // starts at the EV-aligned-to-word element (rowE & ~(BF ? 1 : 0)) + EV * j
+  constexpr int VPR = (IW + (BF ? 1 : 0) + EV - 1) / EV;  // vectors per row
+  for (int t = tid; t < IH * VPR; t += 256) {
+    const int ry = t / VPR, j = t - ry * VPR;
+    const int iy = iy0 + ry;
+    float* dst = sx + ry * LDW;
+    const bool rowok = (unsigned)iy < (unsigned)p.in_h;
+    const int64_t rowE = pbase + (int64_t)iy * p.in_w + ix0;        // element of window column 0 (may lie outside the row)
+    const int sh = BF ? (int)(rowE & 1) : 0;                         // bf16: loads start on a 4-byte word
+    const int64_t e0 = rowE - sh + (int64_t)EV * j;                  // first element of this vector
+    float f[EV];
+#pragma unroll
+    for (int e = 0; e < EV; ++e) f[e] = 0.f;
+    if (rowok && e0 >= 0 && e0 + EV <= pend) {
+      if constexpr (BF) {
+        const uf_h8 raw = *reinterpret_cast<const uf_h8*>(in + e0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[2 * q] = __uint_as_float(raw.w[q] << 16), f[2 * q + 1] = __uint_as_float(raw.w[q] & 0xffff0000u);
+      } else {
+        const uf_f4 raw = *reinterpret_cast<const uf_f4*>(in + e0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = raw.v[e];
+      }
+    } else if (rowok) {  // vector sticks out of the tensor: element-wise
+#pragma unroll
+      for (int e = 0; e < EV; ++e)
+        if (e0 + e >= 0 && e0 + e < pend) f[e] = uf_ld(in, e0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < EV; ++e) {
+      const int rx = EV * j + e - sh;  // window column
+      const int ix = ix0 + rx;
+      if (rx >= 0 && rx < IW) dst[rx] = (rowok && (unsigned)ix < (unsigned)p.in_w) ? f[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int lx = (tid & 31) * 4, ly0 = (tid >> 5) * 4;
+  const int ox = ox0 + lx;
+  if (ox >= p.out_w) return;
+  float acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4 + KH - 1; ++r) {
+    float v[KW + 3];
+#pragma unroll
+    for (int b = 0; b < KW + 3; ++b) v[b] = sx[(ly0 + r) * LDW + lx + b];
+#pragma unroll
+    for (int a = 0; a < KH; ++a) {
+      const int o = r - a;
+      if (o >= 0 && o < 4) {
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[o][c] = fmaf(v[b + c], kf[a][b], acc[o][c]);
+      }
+    }
+  }
+  T* op = out + (int64_t)plane * p.out_h * p.out_w;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oy = oy0 + ly0 + r;
+    if (oy >= p.out_h) break;
+    const int64_t o = (int64_t)oy * p.out_w + ox;
+    if constexpr (BF) {
+      uint16_t h[4];
+      for (int c = 0; c < 4; ++c) uf_st(h, c, acc[r][c]);
+      *reinterpret_cast<uint2*>(op + o) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    } else {
+      *reinterpret_cast<float4*>(op + o) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    }
+  }
+}
+
 template <class T>
 static int upfirdn2d_launch(const T* in, const T* kernel, T* out, int major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
                             int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
@@ -166,6 +279,18 @@ static int upfirdn2d_launch(const T* in, const T* kernel, T* out, int major, int
   if (full_h < 0 || full_w < 0) return FMI_ERR_BAD_ARG;
   p.out_h = full_h / down_y + 1;
   p.out_w = full_w / down_x + 1;
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4 && p.out_w % 4 == 0 && p.out_w >= 128 &&
+      ((uintptr_t)out & (sizeof(T) == 2 ? 7 : 15)) == 0 && ((uintptr_t)in & 3) == 0 && !getenv("FMI_FIRW_OFF")) {
+    p.tile_in_h = p.tile_in_w = 0;
+    p.tiles_x = (p.out_w + FW_TW - 1) / FW_TW;
+    p.tiles_y = (p.out_h + FW_TH - 1) / FW_TH;
+    const int64_t nb = (int64_t)major * p.tiles_x * p.tiles_y;
+    if (nb > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+    if (kh == 4) hipLaunchKernelGGL((upfirdn2d_firw_kernel<T, 4, 4>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    else if (kh == 3) hipLaunchKernelGGL((upfirdn2d_firw_kernel<T, 3, 3>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    else hipLaunchKernelGGL((upfirdn2d_firw_kernel<T, 2, 2>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, in, kernel, out, p);
+    return fmi_launch_status();
+  }
   if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4) {
     p.tile_in_h = p.tile_in_w = 0;
     p.tiles_x = (p.out_w + FIR_TW - 1) / FIR_TW;
