@@ -324,9 +324,38 @@ __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __rest
     y[i] = (v > 0.f ? v : v * alpha) * scale;
   }
 }
+// 16-byte form (C % 4 == 0): the scalar kernel moved 4 bytes per lane and instruction and reached 2.9 TB/s
+__global__ void __launch_bounds__(256) noise_bias_act_vec_kernel(const float4* __restrict__ x, const float* __restrict__ bias,
+                                                                 const float* __restrict__ noise, const float* __restrict__ nw,
+                                                                 float4* __restrict__ y, int64_t total4, int C4, float alpha, float scale) {
+  const float w = (noise && nw) ? nw[0] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / C4;
+    const int c4 = (int)(i - p * C4);
+    float4 v = x[i];
+    const float nz = (noise && nw) ? w * noise[p] : 0.f;
+    float4 b = make_float4(nz, nz, nz, nz);
+    if (bias) {
+      const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+      b.x += bb.x, b.y += bb.y, b.z += bb.z, b.w += bb.w;
+    }
+    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+    v.x = (v.x > 0.f ? v.x : v.x * alpha) * scale;
+    v.y = (v.y > 0.f ? v.y : v.y * alpha) * scale;
+    v.z = (v.z > 0.f ? v.z : v.z * alpha) * scale;
+    v.w = (v.w > 0.f ? v.w : v.w * alpha) * scale;
+    y[i] = v;
+  }
+}
 extern "C" int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise, const float* nw, float* y,
                                       int64_t pixels, int C, float alpha, float scale, void* stream) {
   if (!x || !y || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) == 0) {
+    const int64_t total4 = pixels * (C / 4);
+    hipLaunchKernelGGL(noise_bias_act_vec_kernel, dim3(fmi_bw_grid(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       bias, noise, nw, (float4*)y, total4, C / 4, alpha, scale);
+    return fmi_launch_status();
+  }
   const int64_t total = pixels * C;
   hipLaunchKernelGGL(noise_bias_act_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, bias, noise,
                      nw, y, total, C, alpha, scale);

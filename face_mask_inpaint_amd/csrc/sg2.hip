@@ -13,8 +13,25 @@ __global__ void __launch_bounds__(256) scale_channels_kernel(const float* __rest
     y[i] = x[i] * s[n * C + c];
   }
 }
+__global__ void __launch_bounds__(256) scale_channels_vec_kernel(const float4* __restrict__ x, const float4* __restrict__ s,
+                                                                 float4* __restrict__ y, int64_t PC4, int C4, int64_t total4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t n = i / PC4;
+    float4 v = x[i];
+    const float4 f = s[n * C4 + c4];
+    v.x *= f.x, v.y *= f.y, v.z *= f.z, v.w *= f.w;
+    y[i] = v;
+  }
+}
 extern "C" int fmi_scale_channels_f32(const float* x, const float* s, float* y, int N, int64_t P, int C, void* stream) {
   if (!x || !s || !y || N <= 0 || P <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)s)) & 15) == 0) {
+    const int64_t total4 = (int64_t)N * P * (C / 4);
+    hipLaunchKernelGGL(scale_channels_vec_kernel, dim3(fmi_bw_grid(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)s, (float4*)y, P * (C / 4), C / 4, total4);
+    return fmi_launch_status();
+  }
   const int64_t total = (int64_t)N * P * C;
   hipLaunchKernelGGL(scale_channels_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, P, C, total);
   return fmi_launch_status();
@@ -92,9 +109,38 @@ __global__ void __launch_bounds__(256) noise_bias_act_bwd_kernel(const float* __
     if (threadIdx.x == 0) atomicAdd(gnw, acc);
   }
 }
+__global__ void __launch_bounds__(256) noise_bias_act_bwd_vec_kernel(const float4* __restrict__ g, const float4* __restrict__ y,
+                                                                     const float* __restrict__ noise, float4* __restrict__ gx,
+                                                                     float* __restrict__ gnw, int64_t total4, int C4, float alpha,
+                                                                     float scale) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    float4 v = g[i];
+    const float4 o = y[i];
+    v.x *= scale * (o.x > 0.f ? 1.f : alpha);
+    v.y *= scale * (o.y > 0.f ? 1.f : alpha);
+    v.z *= scale * (o.z > 0.f ? 1.f : alpha);
+    v.w *= scale * (o.w > 0.f ? 1.f : alpha);
+    gx[i] = v;
+    if (noise) acc += ((v.x + v.y) + (v.z + v.w)) * noise[i / C4];
+  }
+  if (noise && gnw) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(gnw, acc);
+  }
+}
 extern "C" int fmi_noise_bias_act_bwd_f32(const float* g, const float* y, const float* noise, float* gx, float* gnw,
                                           int64_t pixels, int C, float alpha, float scale, void* stream) {
   if (!g || !y || !gx || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 == 0 && ((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)gx)) & 15) == 0) {
+    const int64_t total4 = pixels * (C / 4);
+    int grid = fmi_bw_grid(total4, 256 * 4);
+    if (grid > 1024) grid = 1024;  // one atomic per block on a single address
+    hipLaunchKernelGGL(noise_bias_act_bwd_vec_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)y,
+                       noise, (float4*)gx, gnw, total4, C / 4, alpha, scale);
+    return fmi_launch_status();
+  }
   const int64_t total = pixels * C;
   hipLaunchKernelGGL(noise_bias_act_bwd_kernel, dim3(fmi_bw_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, y, noise,
                      gx, gnw, total, C, alpha, scale);
