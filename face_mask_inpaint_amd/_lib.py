@@ -44,6 +44,9 @@ SIGNATURES = {
     "fmi_conv2d_thin_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, vp],
     "fmi_conv2d_thin_dgrad_f32": [PD, vp, vp, vp, vp],
     "fmi_conv2d_thin_input_dgrad_f32": [PD, vp, vp, vp, vp],
+    "fmi_conv2d_thin_lrelu_fwd_f32": [PD, vp, f32, vp, vp, vp, i32, vp],
+    "fmi_conv2d_thin_lrelu_dgrad_f32": [PD, vp, vp, vp, f32, vp, vp],
+    "fmi_conv2d_thin_lrelu_wgrad_f32": [PD, vp, f32, vp, vp, vp, vp],
     "fmi_conv2d_thin_wgrad_f32": [PD, vp, vp, vp, vp, vp],
     "fmi_conv2d_fwd_bf16": [PD, vp, vp, vp, vp, vp, i64, vp],
     "fmi_conv2d_dgrad_bf16": [PD, vp, vp, vp, vp, vp, i64, vp],
@@ -114,7 +117,7 @@ SIGNATURES = {
 STATUS = {0: "ok", 1: "bad argument", 2: "unsupported shape/mode", 3: "kernel launch failed"}
 
 
-PREDICATES = {"fmi_conv2d_thin_supported": [PD], "fmi_conv2d_bf16_supported": [PD]}
+PREDICATES = {"fmi_conv2d_thin_supported": [PD], "fmi_conv2d_bf16_supported": [PD], "fmi_conv2d_thin_lrelu_supported": [PD]}
 
 
 class FmiError(RuntimeError):

@@ -31,7 +31,20 @@ struct ThinArgs {
   float* y;          // [N,H,W,K] pixel pitch ycs
   int N, H, W, C, K, xcs, ycs, pad_mode, act;
   int flip = 0;  // weights indexed with tap 8 - t: the adjoint of a THIN-INPUT convolution (C_in <= 4) is a thin-output convolution of dy
+  // fused input activation: the convolution reads lrelu(x, in_slope) (the Output block: LeakyReLU -> ReflectionPad2d -> conv -> tanh,
+  // base_function.py:367-398): applied while the window is staged (forward / weight gradient, C = 32 LDS kernels only); the adjoint
+  // multiplies its result by lrelu'(xin) -- one pass over the 1 GB activation each instead of two
+  float in_slope = 1.f;
+  const float* xin = nullptr;
 };
+__device__ __forceinline__ float4 lrelu4(float4 v, float s) {
+  v.x = v.x > 0.f ? v.x : v.x * s, v.y = v.y > 0.f ? v.y : v.y * s, v.z = v.z > 0.f ? v.z : v.z * s, v.w = v.w > 0.f ? v.w : v.w * s;
+  return v;
+}
+__device__ __forceinline__ float4 lrelu_mask4(float4 g, float4 x, float s) {
+  g.x *= x.x > 0.f ? 1.f : s, g.y *= x.y > 0.f ? 1.f : s, g.z *= x.z > 0.f ? 1.f : s, g.w *= x.w > 0.f ? 1.f : s;
+  return g;
+}
 
 template <int K>
 __device__ __forceinline__ void load_w(float (&wr)[9][4][K], const float* __restrict__ w, int C, int c0, bool is_wt = false) {
@@ -106,7 +119,10 @@ __global__ void __launch_bounds__(256) thin_dgrad_border_kernel(ThinArgs a, floa
       load_w<K>(wr, a.w, a.C, c0, true);
       cur_c0 = c0;
     }
-    *reinterpret_cast<float4*>(dx + ((int64_t)(n * a.H + qy) * a.W + qx) * a.xcs + c0) = thin_dgrad_pixel<K>(a, wr, n, qy, qx);
+    const int64_t o = ((int64_t)(n * a.H + qy) * a.W + qx) * a.xcs + c0;
+    float4 v = thin_dgrad_pixel<K>(a, wr, n, qy, qx);
+    if (a.xin) v = lrelu_mask4(v, *reinterpret_cast<const float4*>(a.xin + o), a.in_slope);
+    *reinterpret_cast<float4*>(dx + o) = v;
   }
 }
 
@@ -344,6 +360,10 @@ __global__ void __launch_bounds__(256) thin_fwd_lds_kernel(ThinArgs a, int tiles
     stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) stage[j] = *reinterpret_cast<const float4*>(img + ((int64_t)iy * a.W + ix) * a.xcs + 4 * (tid & 7));
   }
+  if (a.in_slope != 1.f) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) stage[j] = lrelu4(stage[j], a.in_slope);
+  }
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
     const int p = (tid >> 3) + 32 * j;
@@ -424,6 +444,10 @@ __global__ void __launch_bounds__(256) thin_wgrad_lds_kernel(ThinArgs a, float* 
       const bool ok = p < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
       stage[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) stage[l] = *reinterpret_cast<const float4*>(img + ((int64_t)iy * a.W + ix) * a.xcs + 4 * (tid & 7));
+    }
+    if (a.in_slope != 1.f) {
+#pragma unroll
+      for (int l = 0; l < NLD; ++l) stage[l] = lrelu4(stage[l], a.in_slope);
     }
     __syncthreads();  // the previous tile's reads of sx are done
 #pragma unroll
@@ -547,7 +571,11 @@ __global__ void __launch_bounds__(256) thin_dgrad_mfma_kernel(ThinArgs a, float*
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int k = 0; k < K; ++k) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[t][k], gv[t][k], acc, 0, 0, 0);
-      if (live) *reinterpret_cast<float4*>(xrow + (int64_t)x * a.xcs) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (live) {
+        float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (a.xin) o = lrelu_mask4(o, *reinterpret_cast<const float4*>(a.xin + (xrow - dx) + (int64_t)x * a.xcs), a.in_slope);
+        *reinterpret_cast<float4*>(xrow + (int64_t)x * a.xcs) = o;
+      }
     }
   }
 }
@@ -571,12 +599,17 @@ bool thin_shape_ok(const fmi_conv_desc* d) {
 // 1 if the thin-output kernels take this geometry (same-size 3x3 stride-1 pad-1 convolution, K <= 4, C = 4..64 power of two)
 extern "C" int fmi_conv2d_thin_supported(const fmi_conv_desc* d) { return d && thin_shape_ok(d) ? 1 : 0; }
 
-extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
-                                       const float* residual, float* y, int act, void* stream) {
+static bool thin_lrelu_ok(const fmi_conv_desc* d) { return thin_shape_ok(d) && d->C == 32 && !getenv("FMI_THIN_NO_LDS"); }
+extern "C" int fmi_conv2d_thin_lrelu_supported(const fmi_conv_desc* d) { return d && thin_lrelu_ok(d) ? 1 : 0; }
+
+static int thin_fwd_impl(const fmi_conv_desc* d, const float* x, float in_slope, const float* wf, const float* bias, const float* residual,
+                         float* y, int act, void* stream) {
   if (!d || !x || !wf || !y || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
   if (!thin_shape_ok(d) || ((uintptr_t)x & 15)) return FMI_ERR_UNSUPPORTED;
+  if (in_slope != 1.f && !thin_lrelu_ok(d)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   ThinArgs a{x, wf, bias, residual, y, d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, act};
+  a.in_slope = in_slope;
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
   if (total >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
@@ -597,13 +630,25 @@ extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, c
   return fmi_launch_status();
 }
 
+extern "C" int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                                       const float* residual, float* y, int act, void* stream) {
+  return thin_fwd_impl(d, x, 1.f, wf, bias, residual, y, act, stream);
+}
+extern "C" int fmi_conv2d_thin_lrelu_fwd_f32(const fmi_conv_desc* d, const float* x, float in_slope, const float* wf, const float* bias,
+                                             float* y, int act, void* stream) {
+  return thin_fwd_impl(d, x, in_slope, wf, bias, nullptr, y, act, stream);
+}
+
 /* dx (layout of x) = adjoint of the thin convolution applied to dy; pad_mode = reflect includes the fold of the padded
  * gradient (what fmi_conv2d_dgrad_f32 on the padded extent + fmi_reflect_pad_fold_f32 compute in two passes). */
-extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream) {
+static int thin_dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, const float* xin, float in_slope, float* dx,
+                           void* stream) {
   if (!d || !dy || !wt || !dx) return FMI_ERR_BAD_ARG;
-  if (!thin_shape_ok(d) || ((uintptr_t)dx & 15)) return FMI_ERR_UNSUPPORTED;
+  if (!thin_shape_ok(d) || ((uintptr_t)dx & 15) || ((uintptr_t)xin & 15)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   ThinArgs a{nullptr, wt, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
+  a.xin = xin;
+  a.in_slope = in_slope;
   int qbits = 0;
   while ((1 << qbits) < d->C / 4) ++qbits;
   {
@@ -617,6 +662,14 @@ extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy
     THIN_DISPATCH(thin_dgrad_border_kernel, a, dx, nb);
   }
   return fmi_launch_status();
+}
+extern "C" int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream) {
+  return thin_dgrad_impl(d, dy, wt, nullptr, 1.f, dx, stream);
+}
+extern "C" int fmi_conv2d_thin_lrelu_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* x, float in_slope,
+                                               float* dx, void* stream) {
+  if (!x) return FMI_ERR_BAD_ARG;
+  return thin_dgrad_impl(d, dy, wt, x, in_slope, dx, stream);
 }
 
 /* Adjoint of a THIN-INPUT convolution (C_in <= 4, e.g. VGG16's first layer 3 -> 64, whose input gradient d loss / d image the
@@ -645,12 +698,13 @@ extern "C" int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const flo
 }
 
 /* dwf[9][C][K] += x^T dy, dbias[k] += sum dy (dbias may be NULL); caller zeroes both. */
-extern "C" int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
-                                         void* stream) {
+static int thin_wgrad_impl(const fmi_conv_desc* d, const float* x, float in_slope, const float* dy, float* dwf, float* dbias, void* stream) {
   if (!d || !x || !dy || !dwf) return FMI_ERR_BAD_ARG;
   if (!thin_shape_ok(d) || ((uintptr_t)x & 15)) return FMI_ERR_UNSUPPORTED;
+  if (in_slope != 1.f && !thin_lrelu_ok(d)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   ThinArgs a{x, nullptr, nullptr, nullptr, const_cast<float*>(dy), d->N, d->H, d->W, d->C, d->K, d->x_cstride, d->y_cstride, d->pad_mode, 0};
+  a.in_slope = in_slope;
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
   if (d->C == 32 && !getenv("FMI_THIN_NO_LDS")) {  // halo tile through LDS, persistent workgroups (3 per CU)
@@ -666,4 +720,12 @@ extern "C" int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x,
   const int grid = (int)(waves / 4 > 1024 ? 1024 : (waves + 3) / 4);
   THIN_DISPATCH(thin_wgrad_kernel, a, dwf, dbias, G, total);
   return fmi_launch_status();
+}
+extern "C" int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,
+                                         void* stream) {
+  return thin_wgrad_impl(d, x, 1.f, dy, dwf, dbias, stream);
+}
+extern "C" int fmi_conv2d_thin_lrelu_wgrad_f32(const fmi_conv_desc* d, const float* x, float in_slope, const float* dy, float* dwf,
+                                               float* dbias, void* stream) {
+  return thin_wgrad_impl(d, x, in_slope, dy, dwf, dbias, stream);
 }

@@ -303,6 +303,62 @@ class _Conv2d(torch.autograd.Function):
         return gx, gwf, gb, gres, None, None, None, None, None, None, None
 
 
+class _ThinConvLReLU(torch.autograd.Function):
+    """y = act(conv3x3(lrelu(x, slope), W) + bias) for a thin-output (K <= 4) stride-1 pad-1 convolution of a 32-channel map: the
+    generator's Output block (base_function.py:386-396) with the LeakyReLU folded into the convolution kernels -- x is read once per
+    direction, lrelu(x) is never written."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bias, wt, slope, pad_mode, act):
+        _chk(x, wf, bias)
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        d, oh, ow = conv_desc(n, h, w, c, k, 3, 3, 1, 1, pad_mode)
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
+        with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k3s1", 2.0 * n * oh * ow * k * c * 9):
+            _L().conv2d_thin_lrelu_fwd_f32(C.byref(d), _p(x), slope, _p(wf), _p(bias), _p(y), act, _st())
+        ctx.save_for_backward(x, wf, y if act else None)
+        ctx.wt, ctx.cfg, ctx.has_b = wt, (slope, pad_mode, act), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _L()
+        x, wf, y = ctx.saved_tensors
+        slope, pad_mode, act = ctx.cfg
+        gy = gy.contiguous()
+        if act:
+            gy = _act_bwd(gy, y, act)
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        d, _, _ = conv_desc(n, h, w, c, k, 3, 3, 1, 1, pad_mode)
+        gx = gwf = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k3s1", 2.0 * gy.numel() * c * 9):
+                lib.conv2d_thin_lrelu_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), _p(x), slope, _p(gx), _st())
+        if ctx.needs_input_grad[1]:
+            gwf = _zeros_like(wf)
+            if ctx.has_b and ctx.needs_input_grad[2]:
+                gb = _zeros(k, x.device, torch.float32)
+            with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k3s1", 2.0 * gy.numel() * c * 9):
+                lib.conv2d_thin_lrelu_wgrad_f32(C.byref(d), _p(x), slope, _p(gy), _p(gwf), _p(gb), _st())
+        elif ctx.has_b and ctx.needs_input_grad[2]:
+            gb = _zeros(k, x.device, torch.float32)
+            lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
+        return gx, gwf, gb, None, None, None, None
+
+
+def lrelu_conv2d(x, pw: PackedWeight, bias=None, slope=0.1, pad=1, pad_mode=0, act=ACT_NONE):
+    """act(conv(lrelu(x, slope))): one fused pass when the thin-output kernels take the shape, LeakyReLU + conv2d otherwise"""
+    if x.dtype == torch.float32 and pw.kh == 3 and pw.kw == 3 and pad == 1 and x.is_cuda:
+        n, h, w, c = x.shape
+        d, _, _ = conv_desc(n, h, w, c, pw.wf.shape[2], 3, 3, 1, 1, pad_mode)
+        if _L().conv2d_thin_lrelu_supported(C.byref(d)) and x.data_ptr() % 16 == 0:
+            return _ThinConvLReLU.apply(x, pw.wf, bias, pw.wt, float(slope), pad_mode, act)
+    return conv2d(leaky_relu(x, slope), pw, bias, None, 1, pad, pad_mode, act)
+
+
 def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE):
     if x.dtype == BF16:
         if bias is not None or residual is not None or pad_mode or act:

@@ -230,9 +230,14 @@ class Output(_NhwcBlock):
 
     def nhwc(self, x):
         with weight_scope(self):
+            conv = _conv(self.conv1)
+            if self._pad == 1 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and conv.dilation == (1, 1):
+                # LeakyReLU, ReflectionPad2d, the convolution and tanh in one kernel (thin-output path); falls back to
+                # LeakyReLU + convolution by itself for shapes that path does not take
+                return FF.lrelu_conv2d(x, packed(conv), conv.bias, self._slope, 1, 1, FF.ACT_TANH)
             h = FF.leaky_relu(x, self._slope)
             # ReflectionPad2d is folded into the gather of the implicit GEMM, tanh into its epilogue
-            return run_conv(_conv(self.conv1), h, act=FF.ACT_TANH, pad_mode=1, pad=self._pad)
+            return run_conv(conv, h, act=FF.ACT_TANH, pad_mode=1, pad=self._pad)
 
 
 class Auto_Attn(nn.Module):

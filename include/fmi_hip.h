@@ -101,6 +101,16 @@ int fmi_conv2d_thin_fwd_f32(const fmi_conv_desc* d, const float* x, const float*
                             const float* residual, float* y, int act, void* stream);
 int fmi_conv2d_thin_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);
 int fmi_conv2d_thin_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias, void* stream);
+/* The same thin-output convolution reading lrelu(x, in_slope) -- the whole Output block LeakyReLU -> ReflectionPad2d(1) -> conv3x3 -> tanh
+ * (base_function.py:386-396) in ONE pass over the activation per direction: the activation is applied while the halo window is staged
+ * (forward, weight gradient), the adjoint multiplies its result by lrelu'(x).  C = 32 only (fmi_conv2d_thin_lrelu_supported). */
+int fmi_conv2d_thin_lrelu_supported(const fmi_conv_desc* d);
+int fmi_conv2d_thin_lrelu_fwd_f32(const fmi_conv_desc* d, const float* x, float in_slope, const float* wf, const float* bias, float* y, int act,
+                                  void* stream);
+int fmi_conv2d_thin_lrelu_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* x, float in_slope, float* dx,
+                                    void* stream);
+int fmi_conv2d_thin_lrelu_wgrad_f32(const fmi_conv_desc* d, const float* x, float in_slope, const float* dy, float* dwf, float* dbias,
+                                    void* stream);
 /* adjoint of a thin-INPUT 3x3 convolution (C <= 4, K = 4..64 a power of two, stride 1, pad 1, zeros): dx = thin-output convolution of
  * dy with flipped taps -- the input gradient of VGG16's first layer (loss.py:45-65); fmi_conv2d_dgrad_f32 routes to it by itself */
 int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream);

@@ -522,6 +522,33 @@ def test_thin_output_conv(dev, FF, n, c, k, h, w, pad_mode, act):
         torch.testing.assert_close(dx2.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c,k,h,w,pad_mode", [(2, 32, 3, 20, 24, 1), (1, 32, 3, 70, 33, 1), (2, 32, 4, 9, 12, 0), (1, 16, 3, 12, 12, 1)])
+def test_output_block_fused_lrelu_conv_tanh(dev, FF, n, c, k, h, w, pad_mode):
+    """FF.lrelu_conv2d = tanh(conv3x3(pad(lrelu(x)))) (base_function.py:386-396) with the LeakyReLU folded into the thin-output
+    kernels (C = 32) or, for other widths, the LeakyReLU + convolution pair: values and all gradients against autograd"""
+    from face_mask_inpaint_amd.functional import PackedWeight
+
+    g = torch.Generator().manual_seed(h * 13 + c + k)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt_ = (torch.randn(k, c, 3, 3, generator=g) / (c * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(k, generator=g, requires_grad=True)
+    a = F.leaky_relu(x, 0.1)
+    ap = F.pad(a, (1, 1, 1, 1), mode="reflect") if pad_mode else F.pad(a, (1, 1, 1, 1))
+    y = torch.tanh(F.conv2d(ap, wt_, b))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    wf, wtp = [t.to(dev) for t in pack(wt_.detach())]
+    wf.requires_grad_(True)
+    xd, bd = nhwc(x.detach()).to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    out = FF.lrelu_conv2d(xd, PackedWeight(wf, wtp, k, c, 3, 3), bd, 0.1, 1, pad_mode, FF.ACT_TANH)
+    torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-5, atol=1e-5)
+    out.backward(nhwc(gy).to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
+    tol = 1e-4 * max(1.0, (n * h * w / 2048.0) ** 0.5)
+    torch.testing.assert_close(wf.grad.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=tol)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=tol)
+
+
 @pytest.mark.parametrize("n,c,k,h,w", [(2, 3, 64, 40, 36), (1, 3, 32, 130, 200), (2, 1, 16, 9, 7), (1, 4, 8, 3, 3), (2, 2, 4, 17, 5)])
 def test_thin_input_conv_adjoint(dev, FF, n, c, k, h, w):
     """input gradient of a thin-INPUT 3x3 convolution (VGG16's first layer 3 -> 64, loss.py:45-65): the dedicated entry and the
