@@ -504,6 +504,7 @@ struct WgArgsB {
   float* dwf;
   ConvGeom g;  // forward geometry: anchors = output pixels, all kh*kw taps
   int Kout, ycs, Mrows, P, kchunk;
+  int tiles, ksplit, xcd_splits;
 };
 
 // LDS image of one operand tile: [32-row group][64 pixels][32 rows] bf16 -- a wave instruction of the copy fills 16 pixels x 64
@@ -518,12 +519,26 @@ __global__ void __launch_bounds__(T::NT) wgrad_bf16_kernel(WgArgsB a, int tiles_
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  // Workgroup -> (pixel split, tile): the workgroups of ONE split share their pixel range (every tile re-reads it for its own rows /
+  // columns), so a split is pinned to one XCD (linear id % 8 = XCD): its tiles stream through the range together and the XCD's L2
+  // serves all re-reads.  With tiles fastest across ALL XCDs, FETCH_SIZE was 2 GB per launch for 134 MB of operands (5 TB/s of fabric
+  // traffic at 0.4 ms).
+  int lid, split;
+  if (a.xcd_splits) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int grp = idx / a.tiles;
+    lid = idx - grp * a.tiles;
+    split = grp * 8 + xcd;
+    if (split >= a.ksplit) return;
+  } else {
+    lid = xcd_remap(blockIdx.x, gridDim.x);
+    split = blockIdx.y;
+  }
   const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
   const ConvGeom& g = a.g;
-  const int k_begin = blockIdx.y * a.kchunk;
+  const int k_begin = split * a.kchunk;
   int k_end = k_begin + a.kchunk;
   if (k_end > a.P) k_end = a.P;
 
@@ -669,9 +684,15 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   if (ksplit > kmax) ksplit = kmax;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 65535) ksplit = 65535;
+  if (ksplit >= 6) ksplit = (ksplit + 4) / 8 * 8;  // splits are dealt to the 8 XCDs in groups of 8: keep the groups full
   a.kchunk = (int)(ceil_div64(ceil_div64(a.P, ksplit), 64) * 64);
   ksplit = ceil_div64(a.P, a.kchunk);
-  const dim3 grid((unsigned)(tm * tn), (unsigned)ksplit);
+  a.tiles = (int)(tm * tn);
+  a.ksplit = (int)ksplit;
+  a.xcd_splits = (ksplit >= 8 && !getenv("FMI_WGRAD_XCD_OFF")) ? 1 : 0;
+  const int64_t nwg = a.xcd_splits ? tm * tn * ceil_div64(ksplit, 8) * 8 : tm * tn;
+  if (nwg > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)nwg, a.xcd_splits ? 1u : (unsigned)ksplit);
   hipStream_t st = (hipStream_t)stream;
   if (bn == 32) hipLaunchKernelGGL((wgrad_bf16_kernel<TB128x32>), grid, dim3(256), 0, st, a, (int)tn);
   else if (bn == 64) hipLaunchKernelGGL((wgrad_bf16_kernel<TB128x64>), grid, dim3(256), 0, st, a, (int)tn);

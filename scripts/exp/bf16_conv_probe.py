@@ -1,7 +1,7 @@
 """bf16 convolution kernels against torch on bf16-rounded operands (fp32 accumulation); prints errors and timings"""
 import ctypes as C, sys, time
 import torch, torch.nn.functional as F
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from face_mask_inpaint_amd import _lib, functional as FF
 
 lib = _lib.lib()

@@ -1,7 +1,7 @@
 """per-launch table of the bf16 decoder forward + backward (event-timed)"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from face_mask_inpaint_amd import functional as FF
 from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator
 dev = torch.device("cuda:0")

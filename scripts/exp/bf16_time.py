@@ -1,7 +1,7 @@
 """timing only: bf16 conv forward / adjoint / weight gradient on the decoder's big layers"""
 import ctypes as C, sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from face_mask_inpaint_amd import _lib, functional as FF
 lib = _lib.lib()
 dev = torch.device("cuda:0")

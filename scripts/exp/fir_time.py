@@ -1,7 +1,7 @@
 """channels-last Blur (upfirdn2d up = down = 1, 4x4) GB/s, fp32 and bf16, decoder shapes"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from face_mask_inpaint_amd import functional as FF
 dev = torch.device("cuda:0")
 k = torch.tensor([1.0, 3.0, 3.0, 1.0])

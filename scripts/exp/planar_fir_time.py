@@ -1,7 +1,7 @@
 """the reference's native upfirdn2d through its drop-in name, planar layout, Blur shapes; GB/s of in + out"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, "/root/repo")
 from face_mask_inpaint_amd.modules.psp.stylegan2.op.upfirdn2d import _native
 dev = torch.device("cuda:0")
 k = torch.tensor([1.0, 3.0, 3.0, 1.0])
