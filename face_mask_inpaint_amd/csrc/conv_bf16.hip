@@ -59,13 +59,17 @@ struct ConvKB {  // A operand: gathered pixels x (tap, channel); a reduction til
     d.boff = ((int64_t)((int)n * g.IH + d.ry) * g.IW + d.rx) * g.cstride + kq;
     return d;
   }
+  // Reduction order: channel chunk (one reduction tile of BK = 1 << g.vec channels) OUTER, tap INNER -- the taps of a chunk re-read
+  // the same pixels, so they follow each other while those bytes are in L2 (tap-major order re-fetched the activation once per tap:
+  // FETCH_SIZE 4x the operand bytes at 512 channels).  g.dC divides by the number of taps here.
   __device__ Tile tile(int k0) const {
-    const int tp = (int)fdiv((uint32_t)k0, g.dC);
+    const int kt = k0 >> g.vec;
+    const int chunk = (int)fdiv((uint32_t)kt, g.dC), tp = kt - chunk * g.ntaps();
     const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
     Tile t;
-    t.dy = tp < g.ntaps() ? g.ystep * i : -0x20000000;
+    t.dy = g.ystep * i;
     t.dx = g.xstep * j;
-    t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * g.cstride + (k0 - tp * g.C);
+    t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * g.cstride + (chunk << g.vec);
     return t;
   }
   __device__ const bf16_t* chunk(const DCtx& d, const Tile& t) const {
@@ -86,11 +90,11 @@ struct ConvWKB {  // B operand: weights packed [Nout][T taps][Cred] (reduction c
   };
   __device__ DCtx dprep(int x, int kq) const { return DCtx{x < Nout ? (int64_t)x * T * g.C + kq : -1}; }
   __device__ Tile tile(int k0) const {
-    const int tp = (int)fdiv((uint32_t)k0, g.dC);
-    if (tp >= g.ntaps()) return Tile{-1};
+    const int kt = k0 >> g.vec;
+    const int chunk = (int)fdiv((uint32_t)kt, g.dC), tp = kt - chunk * g.ntaps();
     const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
     const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
-    return Tile{wtap * g.C + (k0 - tp * g.C)};
+    return Tile{wtap * g.C + (chunk << g.vec)};
   }
   __device__ const bf16_t* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.toff >= 0) ? p + d.off + t.toff : nullptr; }
 };
@@ -416,8 +420,8 @@ extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, co
   g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
   g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = 1; g.xstep = 1;
   g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
-  g.pad_mode = 0; g.vec = 1;
-  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
+  g.pad_mode = 0; g.vec = d->C % 64 == 0 ? 6 : 5;  // log2 of the reduction tile
+  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.nty * g.ntx); g.dntx = make_fastdiv(g.ntx);
   g.img_bs = 0;
   ConvSetB set{};
   set.ph[0].la = ConvKB{x, g};
@@ -455,11 +459,12 @@ extern "C" int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy,
       g.ntx = g.kw0 < d->kw ? (d->kw - g.kw0 + s - 1) / s : 0;
       g.dy0 = (py + d->pad - g.kh0) / s; g.dx0 = (px + d->pad - g.kw0) / s;
       g.ystep = -1; g.xstep = -1; g.khstep = s; g.kwstep = s; g.kw = d->kw;
-      g.pad_mode = 0; g.vec = 1;
-      g.dGW = make_fastdiv(GW); g.dG = make_fastdiv(GH * GW); g.dC = make_fastdiv(g.C);
+      g.pad_mode = 0; g.vec = d->K % 64 == 0 ? 6 : 5;  // log2 of the reduction tile
+      g.dGW = make_fastdiv(GW); g.dG = make_fastdiv(GH * GW);
       g.dntx = make_fastdiv(g.ntx > 0 ? g.ntx : 1);
       g.img_bs = 0;
       if (g.nty == 0 || g.ntx == 0) { g.nty = 0; g.ntx = 1; }
+      g.dC = make_fastdiv(g.nty * g.ntx > 0 ? g.nty * g.ntx : 1);
       ConvPhaseB& P = set.ph[nph++];
       P.la = ConvKB{dy, g};
       P.lb = ConvWKB{wck, g, d->C, d->kh * d->kw};
