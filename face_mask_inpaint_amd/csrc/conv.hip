@@ -63,8 +63,11 @@ static int conv_ksplit(int64_t M, int N, int K) {
     return tiles < 1200 && K >= 2304 ? 3 : 1;
   }
   int64_t ks = ceil_div64(384, tiles);
-  if (ks > K / 256) ks = K / 256;  // at least 16 k-tiles per split
-  return ks < 2 ? 1 : (int)(ks > 16 ? 16 : ks);
+  // at least 16 k-tiles per split; a handful of output tiles (M <= 128 rows: the pSp style heads at 4^2 .. 1^2) only stream the
+  // weights, so more, shorter splits put more loads in flight: 4 k-tiles there
+  const int64_t kmin = (M <= 128 && tiles <= 16) ? 64 : 256;
+  if (ks > K / kmin) ks = K / kmin;
+  return ks < 2 ? 1 : (int)(ks > (kmin == 64 ? 64 : 16) ? (kmin == 64 ? 64 : 16) : ks);
 #endif
 }
 
@@ -135,6 +138,26 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
 #endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;
+#ifndef FMI_HOST_EMU
+  // Strided adjoints of small feature maps (the stride-2 style heads of the pSp encoder: 512 -> 512 at 16^2 .. 2^2) are a few
+  // output tiles per sub-pixel phase with up to 128 reduction tiles each -- 0.25 ms of pure load latency per call.  If any phase
+  // wants a split reduction, dx is initialised once and EVERY phase adds its (partial) sums atomically.
+  bool strided_split = false;
+  if (s > 1 && batch_w == 1) {
+    for (int py = 0; py < s && !strided_split; ++py)
+      for (int px = 0; px < s && !strided_split; ++px) {
+        const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
+        const int kh0 = (py + d->pad) % s, kw0 = (px + d->pad) % s;
+        const int nty = kh0 < d->kh ? (d->kh - kh0 + s - 1) / s : 0, ntx = kw0 < d->kw ? (d->kw - kw0 + s - 1) / s : 0;
+        if (GH > 0 && GW > 0 && conv_ksplit((int64_t)d->N * GH * GW, d->C, (int64_t)nty * ntx * d->K) > 1) strided_split = true;
+      }
+    if (strided_split) {
+      const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
+      hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual, d->C,
+                         d->x_cstride, total);
+    }
+  }
+#endif
   for (int py = 0; py < s; ++py) {
     for (int px = 0; px < s; ++px) {
       const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
@@ -159,6 +182,15 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
                 (int64_t)d->H * d->W * d->x_cstride};
       ep.vec = !getenv("FMI_EP_SCALAR") && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
+      if (strided_split) {
+        ep.bias = nullptr;
+        ep.res = nullptr;
+        ep.act = 3;
+        ep.vec = 0;
+        rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, conv_ksplit(g.Mdim(), d->C, g.Kdim()), (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
       const int ks = (s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1;
       static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
       const bool c3 = !c3_off && !(FMI_EXP & 32) && s == 1 && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 &&

@@ -91,6 +91,9 @@ CONV_CASES = [  # n, c, k, h, w, ksz, stride, pad
     (2, 16, 128, 20, 20, 1, 1, 0), (2, 16, 48, 33, 31, 3, 1, 1), (2, 32, 32, 16, 16, 3, 1, 1), (3, 64, 36, 20, 20, 3, 2, 1),
     (2, 16, 32, 32, 32, 3, 2, 1), (2, 32, 64, 32, 32, 3, 2, 1), (2, 16, 16, 32, 32, 4, 2, 1), (2, 48, 64, 17, 19, 5, 1, 2),
     (4, 32, 32, 128, 128, 3, 1, 1), (2, 256, 256, 24, 24, 3, 1, 1), (1, 512, 128, 14, 14, 3, 1, 1),
+    # stride-2 adjoints of small maps with a deep reduction (the pSp style heads, psp_encoders.py:13-36): split over workgroups, all
+    # sub-pixel phases add into one initialised output (incl. phases of odd extents and the 2x2 -> 1x1 case)
+    (4, 512, 256, 8, 8, 3, 2, 1), (2, 256, 512, 5, 7, 3, 2, 1), (8, 512, 512, 2, 2, 3, 2, 1),
 ]
 
 
