@@ -82,9 +82,9 @@ SIGNATURES = {
     "fmi_maxpool2_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
-    "fmi_instnorm_stats_f32": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_stats_f32": [vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "fmi_instnorm_apply_f32": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
-    "fmi_instnorm_bwd_reduce_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_bwd_reduce_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "fmi_instnorm_bwd_apply_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_reduce_loss_f32": [i32, vp, vp, i64, f32, f32, vp, vp],
     "fmi_reduce_loss_bwd_f32": [i32, vp, vp, i64, f32, f32, vp, vp, vp],
@@ -108,7 +108,7 @@ SIGNATURES = {
     "fmi_noise_bias_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     "fmi_upfirdn2d_nhwc_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fmi_prelu_f32": [vp, vp, vp, i64, i32, vp],
-    "fmi_prelu_bwd_f32": [vp, vp, vp, vp, vp, i64, i32, vp],
+    "fmi_prelu_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "fmi_subsample_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_bias_grad_nchw_f32": [vp, i32, i32, i64, vp, vp],
     "fmi_noise_bias_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],

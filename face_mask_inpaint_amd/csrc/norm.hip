@@ -6,11 +6,30 @@
 // Layout of a workgroup: 256 threads = PL pixel lanes x CG channel groups (4 channels each), CG = C/4.
 #include "common.h"
 
-// pixels per workgroup chunk: 512, grown for large planes so that at most ~2048 workgroups (and fp64 atomics per statistic) exist
-static int rows_per_block(int N, int HW) {
-  int64_t r = 512;
-  while ((int64_t)N * ((HW + r - 1) / r) > 2048 && r < 16384) r *= 2;
+// pixels per workgroup chunk: at least 64, grown until at most `cap` workgroups exist.  With fp64 atomics (no workspace) every
+// workgroup adds 2 C values onto the same 2 C addresses, and those serialise: more workgroups were SLOWER there (cap 2048 from 512-row
+// chunks).  With a partials workspace each workgroup stores its own row and a second launch adds the rows, so the chunk can shrink
+// until ~1024 workgroups stream (the BatchNorm planes of the pSp encoder -- 8192 .. 32768 rows of 256 - 512 channels -- ran on 16 - 64
+// workgroups whose two pixel lanes walked 256 rows each: 50 us of load latency per launch, 200 launches per step).
+static int rows_per_block(int N, int HW, int64_t cap, int64_t r0) {
+  int64_t r = r0;
+  while ((int64_t)N * ((HW + r - 1) / r) > cap && r < (1 << 20)) r *= 2;
   return (int)r;
+}
+// out[g][i] = sum_{p < nparts} ws[(g * nparts + p) * width + i]
+__global__ void __launch_bounds__(256) sum_parts_f64_kernel(const double* __restrict__ ws, double* __restrict__ out, int nparts, int width,
+                                                            int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int64_t g = t / width;
+  const int i = (int)(t - g * width);
+  const double* p = ws + g * nparts * (int64_t)width + i;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int q = 0;
+  for (; q + 3 < nparts; q += 4)
+    a0 += p[(int64_t)q * width], a1 += p[(int64_t)(q + 1) * width], a2 += p[(int64_t)(q + 2) * width], a3 += p[(int64_t)(q + 3) * width];
+  for (; q < nparts; ++q) a0 += p[(int64_t)q * width];
+  out[t] = (a0 + a1) + (a2 + a3);
 }
 
 // sums[n][c][0..1] += (sum f0, sum f1) where (f0,f1) = fn(x, g) per element
@@ -18,7 +37,7 @@ template <int MODE>  // 0: (x, x*x)   1: backward reductions (g', g'*xhat)
 __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, double* __restrict__ sums, int HW,
-                                                        int C, float slope, int rpb) {
+                                                        int C, float slope, int rpb, int to_parts) {
   __shared__ float red[256 * 8];
   const int CG = C >> 2, PL = 256 / CG;
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -92,13 +111,38 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
         s1[e] += red[(l * CG + threadIdx.x) * 8 + 4 + e];
       }
     }
+    if (to_parts) {  // row (n, block) of the partials workspace
+      double* d = sums + (((int64_t)n * gridDim.x + blockIdx.x) * C + threadIdx.x * 4) * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      double* d = sums + ((int64_t)n * C + threadIdx.x * 4 + e) * 2;
-      atomicAdd(d, s0[e]);
-      atomicAdd(d + 1, s1[e]);
+      for (int e = 0; e < 4; ++e) d[2 * e] = s0[e], d[2 * e + 1] = s1[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double* d = sums + ((int64_t)n * C + threadIdx.x * 4 + e) * 2;
+        atomicAdd(d, s0[e]);
+        atomicAdd(d + 1, s1[e]);
+      }
     }
   }
+}
+// launches the reduction; with a workspace of ws_doubles >= N * C * 2 doubles the sums are WRITTEN (partials + one adding launch),
+// without one they are accumulated onto the caller-zeroed buffer by fp64 atomics
+template <int MODE>
+static void launch_in_reduce(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, double* sums,
+                             int N, int HW, int C, float slope, double* ws, int64_t ws_doubles, hipStream_t st) {
+  if (ws && ws_doubles >= (int64_t)N * C * 2 && (((uintptr_t)ws) & 15) == 0) {
+    int64_t cap = ws_doubles / ((int64_t)C * 2);
+    if (cap > 1024) cap = 1024;
+    const int rpb = rows_per_block(N, HW, cap, 64);
+    const int blocks = (HW + rpb - 1) / rpb;
+    hipLaunchKernelGGL((in_reduce_kernel<MODE>), dim3(blocks, N), dim3(256), 0, st, x, gy, stats, gamma, beta, ws, HW, C, slope, rpb, 1);
+    const int64_t total = (int64_t)N * C * 2;
+    hipLaunchKernelGGL(sum_parts_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, sums, blocks, C * 2, total);
+    return;
+  }
+  const int rpb = rows_per_block(N, HW, 2048, 512);
+  hipLaunchKernelGGL((in_reduce_kernel<MODE>), dim3((HW + rpb - 1) / rpb, N), dim3(256), 0, st, x, gy, stats, gamma, beta, sums, HW, C, slope,
+                     rpb, 0);
 }
 
 __global__ void __launch_bounds__(256) in_finalize_kernel(const double* __restrict__ sums, float* __restrict__ stats, int NC,
@@ -118,14 +162,12 @@ static int check_c(int C) {
   return FMI_OK;
 }
 
-extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats, int N, int HW, int C, float eps, void* stream) {
+extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws,
+                                      int64_t ws_doubles, void* stream) {
   if (!x || !sums || !stats || N <= 0 || HW <= 0 || C <= 0 || ((uintptr_t)x & 15)) return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int rpb = rows_per_block(N, HW);
-  dim3 grid((HW + rpb - 1) / rpb, N);
-  hipLaunchKernelGGL((in_reduce_kernel<0>), grid, dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, sums, HW, C, 1.f, rpb);
+  launch_in_reduce<0>(x, nullptr, nullptr, nullptr, nullptr, sums, N, HW, C, 1.f, ws, ws_doubles, st);
   hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const double*)sums, stats, N * C, HW, eps);
   return fmi_launch_status();
 }
@@ -160,13 +202,12 @@ extern "C" int fmi_instnorm_apply_f32(const float* x, const float* stats, const 
 }
 
 extern "C" int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
-                                           const float* beta, double* red, int N, int HW, int C, float slope, void* stream) {
+                                           const float* beta, double* red, int N, int HW, int C, float slope, double* ws,
+                                           int64_t ws_doubles, void* stream) {
   if (!x || !gy || !stats || !gamma || !beta || !red || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)gy & 15))
     return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
-  const int rpb = rows_per_block(N, HW);
-  dim3 grid((HW + rpb - 1) / rpb, N);
-  hipLaunchKernelGGL((in_reduce_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, stats, gamma, beta, red, HW, C, slope, rpb);
+  launch_in_reduce<1>(x, gy, stats, gamma, beta, red, N, HW, C, slope, ws, ws_doubles, (hipStream_t)stream);
   return fmi_launch_status();
 }
 

@@ -273,8 +273,23 @@ __global__ void __launch_bounds__(256) prelu_kernel(const float* __restrict__ x,
     y[i] = v > 0.f ? v : a[i % C] * v;
   }
 }
+__global__ void __launch_bounds__(256) prelu_vec_kernel(const float4* __restrict__ x, const float4* __restrict__ a, float4* __restrict__ y,
+                                                        int64_t total4, int C4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    float4 v = x[i];
+    const float4 s = a[i % C4];
+    v.x = v.x > 0.f ? v.x : s.x * v.x, v.y = v.y > 0.f ? v.y : s.y * v.y, v.z = v.z > 0.f ? v.z : s.z * v.z, v.w = v.w > 0.f ? v.w : s.w * v.w;
+    y[i] = v;
+  }
+}
 extern "C" int fmi_prelu_f32(const float* x, const float* a, float* y, int64_t rows, int C, void* stream) {
   if (!x || !a || !y || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)a)) & 15) == 0) {
+    const int64_t total4 = rows * (C / 4);
+    hipLaunchKernelGGL(prelu_vec_kernel, dim3(fmi_bw_grid(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                       (const float4*)a, (float4*)y, total4, C / 4);
+    return fmi_launch_status();
+  }
   const int64_t total = rows * C;
   hipLaunchKernelGGL(prelu_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, a, y, total, C);
   return fmi_launch_status();
@@ -305,9 +320,81 @@ __global__ void __launch_bounds__(256) prelu_bwd_kernel(const float* __restrict_
     __syncthreads();
   }
 }
-extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, int64_t rows, int C,
-                                 void* stream) {
+// 16-byte form (C/4 a power of two <= 256): 256 threads = (256 / C4) rows x C4 four-channel chunks per pass, two row passes in flight;
+// the scalar kernel walked 64-channel stripes one after the other with a workgroup barrier each (47 us floor per launch)
+__global__ void __launch_bounds__(256) prelu_bwd_vec_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
+                                                            const float4* __restrict__ a, float4* __restrict__ gx, float* __restrict__ ga,
+                                                            int64_t rows, int C4, int64_t rows_per_block, int to_parts) {
+  __shared__ float4 part[256];
+  const int cg = threadIdx.x % C4, rl = threadIdx.x / C4, RL = 256 / C4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  const float4 ac = a[cg];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto one = [&](int64_t r, const float4 xv, const float4 gv) {
+    float4 o;
+    o.x = xv.x > 0.f ? gv.x : ac.x * gv.x, o.y = xv.y > 0.f ? gv.y : ac.y * gv.y;
+    o.z = xv.z > 0.f ? gv.z : ac.z * gv.z, o.w = xv.w > 0.f ? gv.w : ac.w * gv.w;
+    gx[r * C4 + cg] = o;
+    if (xv.x <= 0.f) s.x += gv.x * xv.x;
+    if (xv.y <= 0.f) s.y += gv.y * xv.y;
+    if (xv.z <= 0.f) s.z += gv.z * xv.z;
+    if (xv.w <= 0.f) s.w += gv.w * xv.w;
+  };
+  int64_t r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {
+    const float4 x0 = x[r * C4 + cg], g0 = g[r * C4 + cg], x1 = x[(r + RL) * C4 + cg], g1 = g[(r + RL) * C4 + cg];
+    one(r, x0, g0);
+    one(r + RL, x1, g1);
+  }
+  for (; r < r1; r += RL) one(r, x[r * C4 + cg], g[r * C4 + cg]);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {
+    float4 t = part[threadIdx.x];
+    for (int l = 1; l < RL; ++l) {
+      const float4 v = part[l * C4 + threadIdx.x];
+      t.x += v.x, t.y += v.y, t.z += v.z, t.w += v.w;
+    }
+    if (to_parts) {  // ga = partials workspace: row blockIdx.x
+      reinterpret_cast<float4*>(ga)[(int64_t)blockIdx.x * C4 + threadIdx.x] = t;
+    } else {
+      atomicAdd(ga + 4 * threadIdx.x + 0, t.x);
+      atomicAdd(ga + 4 * threadIdx.x + 1, t.y);
+      atomicAdd(ga + 4 * threadIdx.x + 2, t.z);
+      atomicAdd(ga + 4 * threadIdx.x + 3, t.w);
+    }
+  }
+}
+// out[i] = sum_{p < nparts} ws[p * width + i]
+__global__ void __launch_bounds__(256) sum_parts_f32_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= width) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = 0;
+  for (; q + 3 < nparts; q += 4)
+    a0 += ws[(int64_t)q * width + i], a1 += ws[(int64_t)(q + 1) * width + i], a2 += ws[(int64_t)(q + 2) * width + i],
+        a3 += ws[(int64_t)(q + 3) * width + i];
+  for (; q < nparts; ++q) a0 += ws[(int64_t)q * width + i];
+  out[i] = (a0 + a1) + (a2 + a3);
+}
+extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, float* ws, int64_t ws_floats,
+                                 int64_t rows, int C, void* stream) {
   if (!g || !x || !a || !gx || !ga || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int C4 = C / 4;
+  if (C % 4 == 0 && C4 <= 256 && (C4 & (C4 - 1)) == 0 && ((((uintptr_t)g) | ((uintptr_t)x) | ((uintptr_t)gx) | ((uintptr_t)a)) & 15) == 0) {
+    const bool parts = ws && ws_floats >= C && (((uintptr_t)ws) & 15) == 0;
+    int64_t blocks = ceil_div64(rows, 64);
+    const int64_t cap = parts ? (ws_floats / C < 1024 ? ws_floats / C : 1024) : 256;  // atomics on C addresses serialise: few blocks
+    if (blocks > cap) blocks = cap;
+    const int64_t rpb = ceil_div64(rows, blocks);
+    blocks = ceil_div64(rows, rpb);
+    hipLaunchKernelGGL(prelu_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)x,
+                       (const float4*)a, (float4*)gx, parts ? ws : ga, rows, C4, rpb, parts ? 1 : 0);
+    if (parts) hipLaunchKernelGGL(sum_parts_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, ga, (int)blocks, C);
+    return fmi_launch_status();
+  }
   int64_t blocks = ceil_div64(rows, 128);
   if (blocks > 2048) blocks = 2048;
   const int64_t rpb = ceil_div64(rows, blocks);

@@ -717,15 +717,23 @@ def resize_bilinear(x, oh, ow, mean=None, std=None):
     return _Resize.apply(x, oh, ow, mean, std)
 
 
+def _norm_ws(device, n, c):
+    """(sums [n, c, 2] fp64 -- written by the library --, partials workspace): the statistics reductions store one partial row per
+    workgroup and add the rows in a second launch instead of serialising fp64 atomics"""
+    sums = torch.empty((n, c, 2), device=device, dtype=torch.float64)
+    ws = torch.empty(max(1024, n) * c * 2, device=device, dtype=torch.float64)
+    return sums, ws
+
+
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, slope):
         _chk(x, gamma, beta)
         lib = _L()
         n, h, w, c = x.shape
-        sums = _zeros((n, c, 2), x.device, torch.float64)
+        sums, ws = _norm_ws(x.device, n, c)
         stats = torch.empty((n, c, 2), device=x.device, dtype=torch.float32)
-        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), n, h * w, c, eps, _st())
+        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), n, h * w, c, eps, C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         y = torch.empty_like(x)
         lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), n, h * w, c, slope, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
@@ -738,8 +746,9 @@ class _InstNormAct(torch.autograd.Function):
         x, stats, gamma, beta = ctx.saved_tensors
         n, h, w, c = x.shape
         g = g.contiguous()
-        red = _zeros((n, c, 2), x.device, torch.float64)
-        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), n, h * w, c, ctx.slope, _st())
+        red, ws = _norm_ws(x.device, n, c)
+        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), n, h * w, c, ctx.slope,
+                                    C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         gx = torch.empty_like(x)
         dg = _zeros_like(gamma)
         db = _zeros_like(beta)
@@ -1376,7 +1385,8 @@ class _PReLU(torch.autograd.Function):
         x, a = ctx.saved_tensors
         c = x.shape[-1]
         gx, ga = torch.empty_like(x), _zeros_like(a)
-        _L().prelu_bwd_f32(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), x.numel() // c, c, _st())
+        ws = _parts_ws(x.device, 1024 * c)
+        _L().prelu_bwd_f32(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), _p(ws), ws.numel(), x.numel() // c, c, _st())
         return gx, ga
 
 
@@ -1418,9 +1428,9 @@ class _BatchNormTrain(torch.autograd.Function):
         lib = _L()
         c = x.shape[-1]
         rows = x.numel() // c
-        sums = _zeros((1, c, 2), x.device, torch.float64)
+        sums, ws = _norm_ws(x.device, 1, c)
         stats = torch.empty((1, c, 2), device=x.device, dtype=torch.float32)
-        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), 1, rows, c, eps, _st())
+        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), 1, rows, c, eps, C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         y = torch.empty_like(x)
         lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), 1, rows, c, 1.0, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
@@ -1434,8 +1444,9 @@ class _BatchNormTrain(torch.autograd.Function):
         c = x.shape[-1]
         rows = x.numel() // c
         g = g.contiguous()
-        red = _zeros((1, c, 2), x.device, torch.float64)
-        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), 1, rows, c, 1.0, _st())
+        red, ws = _norm_ws(x.device, 1, c)
+        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), 1, rows, c, 1.0,
+                                    C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
         lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
                                    1, rows, c, 1.0, _st())

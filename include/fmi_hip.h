@@ -283,14 +283,19 @@ int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, int W, int C
 int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW,
                                 const float* ch_std, void* stream);
 /* InstanceNorm2d(affine) (base_function.py:47): stats[n][c] = {mean, rstd}; y = act((x-mean)*rstd*g + b),
- * act = LeakyReLU(slope) fused when slope != 1. */
-int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2] zeroed*/, float* stats /*[N][C][2]*/,
-                           int N, int HW, int C, float eps, void* stream);
+ * act = LeakyReLU(slope) fused when slope != 1.
+ * ws (may be NULL): fp64 partials workspace of ws_doubles >= N*C*2 doubles (contents irrelevant; ~1024*C*2 lets every CU stream).
+ * With it each workgroup stores its partial sums as one row and a second launch adds the rows: sums / red are WRITTEN.  Without it
+ * the workgroups add onto the caller-ZEROED sums / red with fp64 atomics (which serialise per address: slower, and not
+ * bit-reproducible). */
+int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2]*/, float* stats /*[N][C][2]*/,
+                           int N, int HW, int C, float eps, double* ws, int64_t ws_doubles, void* stream);
 int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
                            int N, int HW, int C, float slope, void* stream);
-/* backward of y = lrelu(IN(x)): red[n][c] = {sum g', sum g'*xhat} (zeroed by caller), then gx; dgamma/dbeta += */
+/* backward of y = lrelu(IN(x)): red[n][c] = {sum g', sum g'*xhat} (ws as above), then gx; dgamma/dbeta += */
 int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
-                                const float* beta, double* red, int N, int HW, int C, float slope, void* stream);
+                                const float* beta, double* red, int N, int HW, int C, float slope, double* ws, int64_t ws_doubles,
+                                void* stream);
 int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
                                const float* beta, const double* red, float* gx, float* dgamma, float* dbeta,
                                int N, int HW, int C, float slope, void* stream);
@@ -381,7 +386,10 @@ int fmi_upfirdn2d_nhwc_f32(const float* in, const float* kernel, float* out, int
 
 /* pSp encoder helpers (modules/psp/encoders/helpers.py:56-119), NHWC rows x C */
 int fmi_prelu_f32(const float* x, const float* a, float* y, int64_t rows, int C, void* stream);                 /* nn.PReLU(C) */
-int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga_zeroed, int64_t rows, int C, void* stream);
+/* ws (may be NULL): fp32 partials workspace of ws_floats >= C (contents irrelevant): ga is then WRITTEN; without it ga must be zeroed
+ * and receives fp32 atomics */
+int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, float* ws, int64_t ws_floats, int64_t rows,
+                      int C, void* stream);
 /* MaxPool2d(1, stride) = sub-sampling; backward != 0: x is the output gradient [N,OH,OW,C], y the (fully written) input gradient */
 int fmi_subsample_f32(const float* x, float* y, int N, int H, int W, int C, int stride, int backward, void* stream);
 
