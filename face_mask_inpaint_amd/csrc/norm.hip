@@ -16,20 +16,30 @@ static int rows_per_block(int N, int HW, int64_t cap, int64_t r0) {
   while ((int64_t)N * ((HW + r - 1) / r) > cap && r < (1 << 20)) r *= 2;
   return (int)r;
 }
-// out[g][i] = sum_{p < nparts} ws[(g * nparts + p) * width + i]
-__global__ void __launch_bounds__(256) sum_parts_f64_kernel(const double* __restrict__ ws, double* __restrict__ out, int nparts, int width,
-                                                            int64_t total) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int64_t g = t / width;
-  const int i = (int)(t - g * width);
-  const double* p = ws + g * nparts * (int64_t)width + i;
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  int q = 0;
-  for (; q + 3 < nparts; q += 4)
-    a0 += p[(int64_t)q * width], a1 += p[(int64_t)(q + 1) * width], a2 += p[(int64_t)(q + 2) * width], a3 += p[(int64_t)(q + 3) * width];
-  for (; q < nparts; ++q) a0 += p[(int64_t)q * width];
-  out[t] = (a0 + a1) + (a2 + a3);
+// out[g][i] = sum_{p < nparts} ws[(g * nparts + p) * width + i].  64 columns x 16 row lanes per workgroup, 8 independent loads in
+// flight per thread (one thread per column walking 1024 rows took 37 us: pure load latency, 200 launches per pSp step)
+__global__ void __launch_bounds__(1024) sum_parts_f64_kernel(const double* __restrict__ ws, double* __restrict__ out, int nparts, int width) {
+  __shared__ double part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  const double* p = ws + (int64_t)blockIdx.y * nparts * width + i;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (i < width) {
+    int q = ty;
+    for (; q + 7 * 16 < nparts; q += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(int64_t)(q + 16 * u) * width];
+    }
+    for (; q < nparts; q += 16) a[0] += p[(int64_t)q * width];
+  }
+  part[ty][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (ty == 0 && i < width) {
+    double t = 0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += part[l][tx];
+    out[(int64_t)blockIdx.y * width + i] = t;
+  }
 }
 
 // sums[n][c][0..1] += (sum f0, sum f1) where (f0,f1) = fn(x, g) per element
@@ -136,8 +146,7 @@ static void launch_in_reduce(const float* x, const float* gy, const float* stats
     const int rpb = rows_per_block(N, HW, cap, 64);
     const int blocks = (HW + rpb - 1) / rpb;
     hipLaunchKernelGGL((in_reduce_kernel<MODE>), dim3(blocks, N), dim3(256), 0, st, x, gy, stats, gamma, beta, ws, HW, C, slope, rpb, 1);
-    const int64_t total = (int64_t)N * C * 2;
-    hipLaunchKernelGGL(sum_parts_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const double*)ws, sums, blocks, C * 2, total);
+    hipLaunchKernelGGL(sum_parts_f64_kernel, dim3((C * 2 + 63) / 64, N), dim3(1024), 0, st, (const double*)ws, sums, blocks, C * 2);
     return;
   }
   const int rpb = rows_per_block(N, HW, 2048, 512);

@@ -367,17 +367,28 @@ __global__ void __launch_bounds__(256) prelu_bwd_vec_kernel(const float4* __rest
     }
   }
 }
-// out[i] = sum_{p < nparts} ws[p * width + i]
-__global__ void __launch_bounds__(256) sum_parts_f32_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= width) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int q = 0;
-  for (; q + 3 < nparts; q += 4)
-    a0 += ws[(int64_t)q * width + i], a1 += ws[(int64_t)(q + 1) * width + i], a2 += ws[(int64_t)(q + 2) * width + i],
-        a3 += ws[(int64_t)(q + 3) * width + i];
-  for (; q < nparts; ++q) a0 += ws[(int64_t)q * width + i];
-  out[i] = (a0 + a1) + (a2 + a3);
+// out[i] = sum_{p < nparts} ws[p * width + i]: 64 columns x 16 row lanes per workgroup, 8 loads in flight per thread
+__global__ void __launch_bounds__(1024) sum_parts_f32_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < width) {
+    int q = ty;
+    for (; q + 7 * 16 < nparts; q += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(int64_t)(q + 16 * u) * width + i];
+    }
+    for (; q < nparts; q += 16) a[0] += ws[(int64_t)q * width + i];
+  }
+  part[ty][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (ty == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += part[l][tx];
+    out[i] = t;
+  }
 }
 extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, float* ws, int64_t ws_floats,
                                  int64_t rows, int C, void* stream) {
@@ -392,7 +403,7 @@ extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a,
     blocks = ceil_div64(rows, rpb);
     hipLaunchKernelGGL(prelu_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)x,
                        (const float4*)a, (float4*)gx, parts ? ws : ga, rows, C4, rpb, parts ? 1 : 0);
-    if (parts) hipLaunchKernelGGL(sum_parts_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, ga, (int)blocks, C);
+    if (parts) hipLaunchKernelGGL(sum_parts_f32_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, ga, (int)blocks, C);
     return fmi_launch_status();
   }
   int64_t blocks = ceil_div64(rows, 128);
