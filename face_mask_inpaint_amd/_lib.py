@@ -102,7 +102,7 @@ SIGNATURES = {
     "fmi_fused_bias_act_f32": [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp],
     "fmi_fused_bias_act_bf16": [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp],
     "fmi_scale_channels_f32": [vp, vp, vp, i32, i64, i32, vp],
-    "fmi_scale_channels_gs_f32": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_scale_channels_gs_f32": [vp, vp, vp, vp, i64, i32, i64, i32, vp],
     "fmi_sqsum_last_f32": [vp, vp, i64, i32, vp],
     "fmi_sqsum_last_bwd_f32": [vp, vp, vp, i64, i32, vp],
     "fmi_noise_bias_act_bwd_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],

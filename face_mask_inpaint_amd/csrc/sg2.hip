@@ -36,9 +36,12 @@ extern "C" int fmi_scale_channels_f32(const float* x, const float* s, float* y, 
   hipLaunchKernelGGL(scale_channels_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, P, C, total);
   return fmi_launch_status();
 }
-// gs[n][c] += sum_p g[n][p][c] * x[n][p][c]     (caller zeroes gs)
+// gs[n][c] = sum_p g[n][p][c] * x[n][p][c].  With a partials workspace (ws_floats >= N*C) every row block stores its sums as one row
+// and a second launch adds the rows (gs WRITTEN); without one the blocks add onto the caller-zeroed gs with fp32 atomics, which
+// serialise per address (52 us per launch on the SE gates of the pSp encoder).
 __global__ void __launch_bounds__(256) scale_channels_gs_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                                float* __restrict__ gs, int64_t P, int C, int64_t rows_per_block) {
+                                                                float* __restrict__ gs, int64_t P, int C, int64_t rows_per_block,
+                                                                int to_parts) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.y;
@@ -47,24 +50,57 @@ __global__ void __launch_bounds__(256) scale_channels_gs_kernel(const float* __r
   if (r1 > P) r1 = P;
   const float* gb = g + (int64_t)n * P * C;
   const float* xb = x + (int64_t)n * P * C;
+  float* dst = to_parts ? gs + ((int64_t)n * gridDim.x + blockIdx.x) * C : gs + (int64_t)n * C;
   for (int cg = 0; cg < C; cg += 64) {
     const int c = cg + tx;
-    float s = 0.f;
-    if (c < C)
-      for (int64_t r = r0 + ty; r < r1; r += 4) s += gb[r * C + c] * xb[r * C + c];
-    part[ty][tx] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      int64_t r = r0 + ty;
+      for (; r + 4 < r1; r += 8) {  // two independent pairs of loads in flight
+        const float a0 = gb[r * C + c], b0 = xb[r * C + c], a1 = gb[(r + 4) * C + c], b1 = xb[(r + 4) * C + c];
+        s0 = fmaf(a0, b0, s0), s1 = fmaf(a1, b1, s1);
+      }
+      for (; r < r1; r += 4) s0 = fmaf(gb[r * C + c], xb[r * C + c], s0);
+    }
+    part[ty][tx] = s0 + s1;
     __syncthreads();
-    if (ty == 0 && c < C) atomicAdd(gs + (int64_t)n * C + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0 && c < C) {
+      const float t = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
+      if (to_parts) dst[c] = t;
+      else atomicAdd(dst + c, t);
+    }
     __syncthreads();
   }
 }
-extern "C" int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, int N, int64_t P, int C, void* stream) {
+// out[n][c] = sum_{b < nparts} ws[(n * nparts + b) * C + c]
+__global__ void __launch_bounds__(256) scale_channels_gs_finish_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int C,
+                                                                       int total) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int n = t / C, c = t - n * C;
+  const float* p = ws + (int64_t)n * nparts * C + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int q = 0;
+  for (; q + 3 < nparts; q += 4) a0 += p[(int64_t)q * C], a1 += p[(int64_t)(q + 1) * C], a2 += p[(int64_t)(q + 2) * C], a3 += p[(int64_t)(q + 3) * C];
+  for (; q < nparts; ++q) a0 += p[(int64_t)q * C];
+  out[t] = (a0 + a1) + (a2 + a3);
+}
+extern "C" int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, float* ws, int64_t ws_floats, int N, int64_t P, int C,
+                                         void* stream) {
   if (!g || !x || !gs || N <= 0 || P <= 0 || C <= 0 || N > 65535) return FMI_ERR_BAD_ARG;
+  const bool parts = ws && ws_floats >= (int64_t)N * C;
   int64_t blocks = ceil_div64(P, 128);
-  if (blocks > 1024) blocks = 1024;
+  int64_t cap = parts ? ws_floats / ((int64_t)N * C) : 1024;
+  const int64_t want = ceil_div64(2048, N);
+  if (parts && cap > want) cap = want;
+  if (blocks > cap) blocks = cap;
   const int64_t rpb = ceil_div64(P, blocks);
   blocks = ceil_div64(P, rpb);
-  hipLaunchKernelGGL(scale_channels_gs_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, g, x, gs, P, C, rpb);
+  hipLaunchKernelGGL(scale_channels_gs_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, g, x, parts ? ws : gs, P, C, rpb,
+                     parts ? 1 : 0);
+  if (parts)
+    hipLaunchKernelGGL(scale_channels_gs_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, gs, (int)blocks, C,
+                       N * C);
   return fmi_launch_status();
 }
 

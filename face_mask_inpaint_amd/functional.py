@@ -1190,8 +1190,9 @@ class _ScaleChannels(torch.autograd.Function):
             ws = _parts_ws(x.device, max(2048, n) * c)
             _L().scale_channels_gs_bf16(_p(g), _p(x), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
         elif ctx.needs_input_grad[1]:
-            gs = _zeros_like(s)
-            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), n, p, c, _st())
+            gs = torch.empty_like(s)
+            ws = _parts_ws(x.device, max(2048, n) * c)
+            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
         return gx, gs
 
 

@@ -373,7 +373,9 @@ int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise
  * demod[n,o] * conv(x * s[n,c], W): algebraically the reference's per-sample weight modulation (model.py:244-250).
  * ---------------------------------------------------------------------- */
 int fmi_scale_channels_f32(const float* x, const float* s, float* y, int N, int64_t P, int C, void* stream);       /* y[n,p,c] = x * s[n,c] */
-int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, int N, int64_t P, int C, void* stream);   /* gs[n,c] += sum_p g*x */
+/* gs[n,c] = sum_p g*x: written when a partials workspace ws (ws_floats >= N*C, contents irrelevant) is given, else += by atomics onto
+ * a caller-zeroed gs */
+int fmi_scale_channels_gs_f32(const float* g, const float* x, float* gs, float* ws, int64_t ws_floats, int N, int64_t P, int C, void* stream);
 int fmi_sqsum_last_f32(const float* x, float* out, int64_t rows, int k, void* stream);                             /* out[r] = sum_k x[r,k]^2 */
 int fmi_sqsum_last_bwd_f32(const float* x, const float* g, float* gx, int64_t rows, int k, void* stream);
 /* backward of fmi_noise_bias_act_f32: gx = g*scale*(y>0?1:alpha); gnw[0] += sum gx*noise[p] (noise/gnw may be NULL) */
