@@ -83,6 +83,7 @@ SIGNATURES = {
     "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "fmi_instnorm_stats_f32": [vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
+    "fmi_batchnorm_running_update_f32": [vp, vp, vp, vp, i32, i64, f32, f32, vp],
     "fmi_instnorm_apply_f32": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_instnorm_bwd_reduce_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "fmi_instnorm_bwd_apply_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

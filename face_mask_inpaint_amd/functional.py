@@ -1454,6 +1454,16 @@ class _BatchNormTrain(torch.autograd.Function):
         return gx, dg, db, None
 
 
+def batch_norm_running_update(stats, running_mean, running_var, num_batches_tracked, count, eps, momentum):
+    """in-place momentum update of the BatchNorm2d buffers from stats [1, C, 2] = (mean, rstd) of the batch (one launch)"""
+    _chk(stats, running_mean, running_var)
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise FmiError("num_batches_tracked must be an int64 device tensor")
+    nbt = C.c_void_p(num_batches_tracked.data_ptr()) if num_batches_tracked is not None else None
+    _L().batchnorm_running_update_f32(_p(stats), _p(running_mean), _p(running_var), nbt, running_mean.numel(), int(count), float(eps),
+                                      float(momentum), _st())
+
+
 def batch_norm_train(x, gamma, beta, eps=1e-5):
     return _BatchNormTrain.apply(x, gamma, beta, float(eps))
 

@@ -40,8 +40,12 @@ def batch_norm(bn: BatchNorm2d, x):
     if bn.training or not bn.track_running_stats:
         y, stats = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps)
         if bn.training and bn.track_running_stats:
-            with torch.no_grad():  # running-statistics bookkeeping on [C] vectors
-                cnt = x.numel() // x.shape[-1]
+            cnt = x.numel() // x.shape[-1]
+            if bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
+                with torch.no_grad():  # one launch: momentum update of both buffers and the batch counter
+                    FF.batch_norm_running_update(stats, bn.running_mean, bn.running_var, bn.num_batches_tracked, cnt, bn.eps, bn.momentum)
+                return y
+            with torch.no_grad():  # cumulative moving average (momentum=None): [C]-sized torch bookkeeping
                 mean = stats[0, :, 0]
                 var = (1.0 / stats[0, :, 1] ** 2 - bn.eps) * (cnt / max(cnt - 1, 1))
                 m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)

@@ -292,6 +292,10 @@ int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2]*/, float* st
                            int N, int HW, int C, float eps, double* ws, int64_t ws_doubles, void* stream);
 int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
                            int N, int HW, int C, float slope, void* stream);
+/* nn.BatchNorm2d running statistics (helpers.py:83-113 run BatchNorm2d in training mode) from stats[C][2] = (mean, rstd) of the batch:
+ * running = (1 - momentum) * running + momentum * (mean | unbiased variance), num_batches_tracked[0] += 1 (may be NULL) */
+int fmi_batchnorm_running_update_f32(const float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
+                                     int64_t count, float eps, float momentum, void* stream);
 /* backward of y = lrelu(IN(x)): red[n][c] = {sum g', sum g'*xhat} (ws as above), then gx; dgamma/dbeta += */
 int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
                                 const float* beta, double* red, int N, int HW, int C, float slope, double* ws, int64_t ws_doubles,
