@@ -4,6 +4,10 @@
 #include "conv3x3.h"
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static bool ep_scalar() {  // debug: FMI_EP_SCALAR = never use the 16-byte epilogue (read once)
+  static const bool v = getenv("FMI_EP_SCALAR") != nullptr;
+  return v;
+}
 
 static int check_desc(const fmi_conv_desc* d) {
   if (!d) return FMI_ERR_BAD_ARG;
@@ -88,7 +92,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   ConvWX lb{wf, g, w_bstride, d->K, (d->K % 4 == 0) && aligned16(wf) && (w_bstride % 4 == 0)};
   ConvEp ep{y, bias, residual, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, act, g.dGW, g.dG,
             (int64_t)d->OH * d->OW * d->y_cstride};
-  ep.vec = !getenv("FMI_EP_SCALAR") && d->K % 4 == 0 && d->y_cstride % 4 == 0 && aligned16(y) && aligned16(bias) && aligned16(residual);
+  ep.vec = !ep_scalar() && d->K % 4 == 0 && d->y_cstride % 4 == 0 && aligned16(y) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
   const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
   static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
@@ -180,7 +184,7 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
       ConvWX lb{wt, g, w_bstride, d->C, (d->C % 4 == 0) && aligned16(wt) && (w_bstride % 4 == 0)};
       ConvEp ep{dx, bias, residual, GH, GW, s, py, px, d->H, d->W, d->x_cstride, 0, g.dGW, g.dG,
                 (int64_t)d->H * d->W * d->x_cstride};
-      ep.vec = !getenv("FMI_EP_SCALAR") && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual);
+      ep.vec = !ep_scalar() && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
       if (strided_split) {
         ep.bias = nullptr;

@@ -694,7 +694,8 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   ksplit = ceil_div64(a.P, a.kchunk);
   a.tiles = (int)(tm * tn);
   a.ksplit = (int)ksplit;
-  a.xcd_splits = (ksplit >= 8 && !getenv("FMI_WGRAD_XCD_OFF")) ? 1 : 0;
+  static const bool xcd_off = getenv("FMI_WGRAD_XCD_OFF") != nullptr;  // debug: splits in grid.y, tiles over all XCDs
+  a.xcd_splits = (ksplit >= 8 && !xcd_off) ? 1 : 0;
   const int64_t nwg = a.xcd_splits ? tm * tn * ceil_div64(ksplit, 8) * 8 : tm * tn;
   if (nwg > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)nwg, a.xcd_splits ? 1u : (unsigned)ksplit);

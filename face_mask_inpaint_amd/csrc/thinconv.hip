@@ -599,7 +599,11 @@ bool thin_shape_ok(const fmi_conv_desc* d) {
 // 1 if the thin-output kernels take this geometry (same-size 3x3 stride-1 pad-1 convolution, K <= 4, C = 4..64 power of two)
 extern "C" int fmi_conv2d_thin_supported(const fmi_conv_desc* d) { return d && thin_shape_ok(d) ? 1 : 0; }
 
-static bool thin_lrelu_ok(const fmi_conv_desc* d) { return thin_shape_ok(d) && d->C == 32 && !getenv("FMI_THIN_NO_LDS"); }
+static bool thin_no_lds() {  // debug: FMI_THIN_NO_LDS = never use the LDS halo kernels (read once)
+  static const bool v = getenv("FMI_THIN_NO_LDS") != nullptr;
+  return v;
+}
+static bool thin_lrelu_ok(const fmi_conv_desc* d) { return thin_shape_ok(d) && d->C == 32 && !thin_no_lds(); }
 extern "C" int fmi_conv2d_thin_lrelu_supported(const fmi_conv_desc* d) { return d && thin_lrelu_ok(d) ? 1 : 0; }
 
 static int thin_fwd_impl(const fmi_conv_desc* d, const float* x, float in_slope, const float* wf, const float* bias, const float* residual,
@@ -615,7 +619,7 @@ static int thin_fwd_impl(const fmi_conv_desc* d, const float* x, float in_slope,
   if (total >= (1ll << 31)) return FMI_ERR_UNSUPPORTED;
   int qbits = 0;
   while ((1 << qbits) < G) ++qbits;
-  if (d->C == 32 && !getenv("FMI_THIN_NO_LDS")) {  // halo tile through LDS
+  if (d->C == 32 && !thin_no_lds()) {  // halo tile through LDS
     const int tiles_x = (d->W + LT_W - 1) / LT_W, tiles_y = (d->H + LT_H - 1) / LT_H;
     const int64_t nb = (int64_t)d->N * tiles_x * tiles_y;
     if (nb < (1ll << 31)) {
@@ -707,7 +711,7 @@ static int thin_wgrad_impl(const fmi_conv_desc* d, const float* x, float in_slop
   a.in_slope = in_slope;
   const int G = d->C / 4;
   const int64_t total = (int64_t)d->N * d->H * d->W;
-  if (d->C == 32 && !getenv("FMI_THIN_NO_LDS")) {  // halo tile through LDS, persistent workgroups (3 per CU)
+  if (d->C == 32 && !thin_no_lds()) {  // halo tile through LDS, persistent workgroups (3 per CU)
     const int tiles_x = (d->W + LT_W - 1) / LT_W, tiles_y = (d->H + LT_H - 1) / LT_H;
     const int64_t nt = (int64_t)d->N * tiles_x * tiles_y;
     if (nt < (1ll << 31)) {

@@ -267,6 +267,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict
   }
 }
 
+static bool firw_off() {  // debug: FMI_FIRW_OFF = never use the wide FIR path (read once)
+  static const bool v = getenv("FMI_FIRW_OFF") != nullptr;
+  return v;
+}
+
 template <class T>
 static int upfirdn2d_launch(const T* in, const T* kernel, T* out, int major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
                             int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
@@ -280,7 +285,7 @@ static int upfirdn2d_launch(const T* in, const T* kernel, T* out, int major, int
   p.out_h = full_h / down_y + 1;
   p.out_w = full_w / down_x + 1;
   if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == kw && kh >= 2 && kh <= 4 && p.out_w % 4 == 0 && p.out_w >= 128 &&
-      ((uintptr_t)out & (sizeof(T) == 2 ? 7 : 15)) == 0 && ((uintptr_t)in & 3) == 0 && !getenv("FMI_FIRW_OFF")) {
+      ((uintptr_t)out & (sizeof(T) == 2 ? 7 : 15)) == 0 && ((uintptr_t)in & 3) == 0 && !firw_off()) {
     p.tile_in_h = p.tile_in_w = 0;
     p.tiles_x = (p.out_w + FW_TW - 1) / FW_TW;
     p.tiles_y = (p.out_h + FW_TH - 1) / FW_TH;
