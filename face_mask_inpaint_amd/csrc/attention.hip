@@ -16,35 +16,36 @@
 //    reference by more than 20 (fp32 has the range; p <= e^20), which happens in the first tiles only; the branch is
 //    wave-uniform.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ATT_THR 20.0f
 
-template <int D, int CT, int NKL, int NVL>
+template <int D, int CT, int NKL, int NVL, int NTH>
 __device__ __forceinline__ void att_gload(float4 (&rk)[NKL], float4 (&rv)[NVL], const float* __restrict__ qb,
                                           const float* __restrict__ v1b, const float* __restrict__ v2b, int C1, int C2, int k0,
                                           int tid) {
 #pragma unroll
   for (int i = 0; i < NKL; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + NTH * i;
     const int key = f / (D / 4), dq = f % (D / 4);
     rk[i] = (f < 8 * D) ? *reinterpret_cast<const float4*>(qb + (int64_t)(k0 + key) * D + dq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < NVL; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + NTH * i;
     const int key = f / (CT / 4), c = (f % (CT / 4)) * 4;
     rv[i] = (c < C1) ? *reinterpret_cast<const float4*>(v1b + (int64_t)(k0 + key) * C1 + c)
                      : *reinterpret_cast<const float4*>(v2b + (int64_t)(k0 + key) * C2 + (c - C1));
   }
 }
-template <int D, int CT, int NKL, int NVL, int LDK>
+template <int D, int CT, int NKL, int NVL, int LDK, int NTH>
 __device__ __forceinline__ void att_lstore(const float4 (&rk)[NKL], const float4 (&rv)[NVL], float* __restrict__ kt,
                                            float* __restrict__ vs, int tid) {
 #pragma unroll
   for (int i = 0; i < NKL; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + NTH * i;
     if (f < 8 * D) {
       const int key = f / (D / 4), dd = (f % (D / 4)) * 4;
       kt[(dd + 0) * LDK + key] = rk[i].x;
@@ -55,28 +56,33 @@ __device__ __forceinline__ void att_lstore(const float4 (&rk)[NKL], const float4
   }
 #pragma unroll
   for (int i = 0; i < NVL; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + NTH * i;
     *reinterpret_cast<float4*>(vs + f * 4) = rv[i];  // f*4 = key*CT + c
   }
 }
 
-template <int D, int NCT>
-__global__ void __launch_bounds__(256, 1) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ v1,
+// NW waves per workgroup, each owning 32 queries; all share the staged key / value tiles.  NW = 8 for long sequences: the 82 KB of LDS
+// allow one workgroup per CU, and with four waves every SIMD held ONE wave whose softmax (exp, max, rescale) left the matrix pipe
+// idle; eight waves put two on each SIMD.  NW = 2 for short ones (T = 1024: 64 workgroups of four waves filled a quarter of the chip).
+template <int D, int NCT, int NW>
+__global__ void __launch_bounds__(NW * 64, 1) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ v1,
                                                           const float* __restrict__ v2, float* __restrict__ o1,
                                                           float* __restrict__ o2, float* __restrict__ lse, int T, int C1,
                                                           int C2) {
   constexpr int CT = NCT * 32;        // total value channels
   constexpr int LDK = 33;             // Kt row pitch (floats)
   constexpr int KT_FLOATS = D * LDK, VS_FLOATS = 32 * CT;
-  constexpr int NKL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1;   // float4 loads per thread for a K tile
-  constexpr int NVL = (8 * CT) / 256;                          // float4 loads per thread for a V tile
+  constexpr int NTH = NW * 64;
+  constexpr int NKL = (8 * D + NTH - 1) / NTH;                 // float4 loads per thread for a K tile
+  constexpr int NVL = (8 * CT) / NTH;                          // float4 loads per thread for a V tile
+  static_assert((8 * CT) % NTH == 0, "whole float4 passes over the V tile");
   __shared__ __attribute__((aligned(16))) float lds[2 * (KT_FLOATS + VS_FLOATS)];
   float* Kt = lds;
   float* Vs = lds + 2 * KT_FLOATS;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int n = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wid * 32;
   const float* qb = q + (int64_t)n * T * D;
   const float* v1b = v1 + (int64_t)n * T * C1;
   const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
@@ -94,13 +100,13 @@ __global__ void __launch_bounds__(256, 1) attn_fwd_kernel(const float* __restric
   float mref = -INFINITY, lsum = 0.f;
 
   float4 rk[NKL], rv[NVL];
-  att_gload<D, CT, NKL, NVL>(rk, rv, qb, v1b, v2b, C1, C2, 0, tid);
-  att_lstore<D, CT, NKL, NVL, LDK>(rk, rv, Kt, Vs, tid);
+  att_gload<D, CT, NKL, NVL, NTH>(rk, rv, qb, v1b, v2b, C1, C2, 0, tid);
+  att_lstore<D, CT, NKL, NVL, LDK, NTH>(rk, rv, Kt, Vs, tid);
   __syncthreads();
   int buf = 0;
   for (int k0 = 0; k0 < T; k0 += 32) {
     // unconditional prefetch (the last iteration re-reads its own tile): a conditional one sends rk/rv to scratch
-    att_gload<D, CT, NKL, NVL>(rk, rv, qb, v1b, v2b, C1, C2, k0 + 32 < T ? k0 + 32 : k0, tid);
+    att_gload<D, CT, NKL, NVL, NTH>(rk, rv, qb, v1b, v2b, C1, C2, k0 + 32 < T ? k0 + 32 : k0, tid);
     const float* kt = Kt + buf * KT_FLOATS + l31;
     const float* vs = Vs + buf * VS_FLOATS + l31;
     // S^T[key][query] for 32 keys x this wave's 32 queries
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(256, 1) attn_fwd_kernel(const float* __restric
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * CT + c * 32], st[s], acc[c], 0, 0, 0);
     }
-    att_lstore<D, CT, NKL, NVL, LDK>(rk, rv, Kt + (buf ^ 1) * KT_FLOATS, Vs + (buf ^ 1) * VS_FLOATS, tid);
+    att_lstore<D, CT, NKL, NVL, LDK, NTH>(rk, rv, Kt + (buf ^ 1) * KT_FLOATS, Vs + (buf ^ 1) * VS_FLOATS, tid);
     __syncthreads();
     buf ^= 1;
   }
@@ -168,11 +174,19 @@ extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const floa
                                      int N, int T, int D, int C1, int C2, void* stream) {
   if (!q || !v1 || !o1 || N <= 0 || T <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && (!v2 || !o2))) return FMI_ERR_BAD_ARG;
   if (T % 128 != 0 || C1 % 32 != 0 || C2 % 32 != 0 || N > 65535) return FMI_ERR_UNSUPPORTED;
+  static const int nw_dbg = getenv("FMI_ATT_NW") ? atoi(getenv("FMI_ATT_NW")) : 0;  // debug: force 2 / 4 / 8 waves per workgroup
+  int nw = (T % 256 == 0 && (int64_t)(T / 256) * N >= 256) ? 8 : ((int64_t)(T / 128) * N < 256 ? 2 : 4);
+  if (nw_dbg == 2 || nw_dbg == 4 || (nw_dbg == 8 && T % 256 == 0)) nw = nw_dbg;
   if ((((uintptr_t)q | (uintptr_t)v1 | (uintptr_t)v2 | (uintptr_t)o1 | (uintptr_t)o2) & 15) != 0) return FMI_ERR_BAD_ARG;
   const int nct = (C1 + C2) / 32;
-  const dim3 grid(T / 128, N), block(256);
+  const dim3 grid(T / (nw * 32), N), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;
-#define ATT_LAUNCH(DD, NN) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2)
+#define ATT_LAUNCH(DD, NN)                                                                                                    \
+  do {                                                                                                                        \
+    if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 8>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2);      \
+    else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 2>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2); \
+    else hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 4>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2);              \
+  } while (0)
   if (D == 64 && nct == 8) ATT_LAUNCH(64, 8);
   else if (D == 32 && nct == 8) ATT_LAUNCH(32, 8);
   else if (D == 32 && nct == 4) ATT_LAUNCH(32, 4);
