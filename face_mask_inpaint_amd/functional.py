@@ -185,6 +185,7 @@ class _WeightPrepare(torch.autograd.Function):
         lib.weight_prepare_f32(entries, n, _st())
         ctx.metas, ctx.ws, ctx.sig = metas, ws, sig
         ctx.mark_non_differentiable(sig, *wts)
+        ctx.set_materialize_grads(False)  # packs that received no gradient arrive as None, not as freshly zero-filled tensors
         return (sig,) + tuple(wfs) + tuple(wts)
 
     @staticmethod
