@@ -623,7 +623,9 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
                      delta_scratch, rows);
   const int nct = (C1 + C2) / 32;
   const dim3 block(256);
-  if (T % 128 == 0) {  // second structure: one key block per wave, fragments in registers, 4x fewer atomics
+  static const int bwd_dbg = getenv("FMI_ATT_BWD") ? atoi(getenv("FMI_ATT_BWD")) : 0;  // debug: 1 / 2 force a structure
+  const bool small = (int64_t)(T / 128) * N < 128;  // short sequences: the first structure has 4x the workgroups
+  if (T % 128 == 0 && bwd_dbg != 1 && (bwd_dbg == 2 || !small)) {  // second structure: one key block per wave, fragments in registers, 4x fewer atomics
     const dim3 grid2(T / 128, N);
     auto lds2 = [](int d, int ct) {
       return sizeof(float) * (size_t)(32 * (ct + 1) + 32 * (d + 1) + 64 + 4 * 32 * (d + 1) + 4 * 32 * 33 + 4 * (d / 32) * 16 * 64);
