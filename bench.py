@@ -30,8 +30,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP
 # HBM-side bytes per launch of the dominant kernel, from the rocprofv3 PMC passes committed under profiles/
 # (round1_pmc_attention.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as the guide
 # prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE counts the fp32 atomics of the dQ tiles exactly).
-PMC_TRAFFIC_BYTES = {"attn_fused_bwd|T16384 d64 C256 b8": 2 * 746413.3 * 1024 + 4456448.0 * 1024,   # attn_bwd2_kernel<64,8>
-                     "attn_fused_fwd|T16384 d64 C256 b8": 2 * 670483.5 * 1024 + 131584.0 * 1024}
+PMC_TRAFFIC_BYTES = {"attn_fused_bwd|T16384 d64 C256 b8": 2 * 746038.0 * 1024 + 4456448.0 * 1024,   # attn_bwd2_kernel<64,8>
+                     "attn_fused_fwd|T16384 d64 C256 b8": 2 * 671539.1 * 1024 + 134025.2 * 1024}   # attn_fwd_kernel<64,8,8>
 ENC = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
 DEC = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
 DISC = dict(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
