@@ -250,7 +250,9 @@ def test_early_discriminator_schedule_equals_reference_order(dev, golden):
     for key in ("G", "D"):
         assert ca[key].keys() == cb[key].keys()
         for n, g in ca[key].items():
-            err, lim = float((cb[key][n] - g).abs().max()), 1e-4 * float(g.abs().max()) + 1e-9
+            # the two runs differ only by the summation order of the fp32 atomics (split reductions, weight gradients), which the
+            # tiny model's conditioning amplifies; a wrong schedule would be off by O(1)
+            err, lim = float((cb[key][n] - g).abs().max()), 3e-4 * float(g.abs().max()) + 3e-9
             assert err <= lim, f"{key}.{n}: {err:.3e} > {lim:.3e}"
     for a, b in zip(la[0], lb[0]):
         assert abs(a - b) <= 1e-6 * abs(a) + 1e-12
