@@ -925,8 +925,11 @@ class _SelfAttention(torch.autograd.Function):
             with _prof(f"attn_fused_fwd|T{t} d{d} C{c1 + c2} b{n}", 2.0 * n * t * t * (d + c1 + c2)):
                 _L().attention_fwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if len(vs) > 1 else None, _p(outs[0]),
                                        _p(outs[1]) if len(vs) > 1 else None, _p(lse), n, t, d, c1, c2, _st())
-            ctx.save_for_backward(q, *vs)
-            ctx.lse, ctx.outs = lse, outs
+            # the outputs go through save_for_backward: as plain ctx attributes they would close a reference cycle through their
+            # own grad_fn (node -> ctx -> output -> node) that Python's collector cannot see -- one whole discriminator graph leaked
+            # per training step (150 MB)
+            ctx.save_for_backward(q, *vs, lse, *outs)
+            ctx.nv = len(vs)
             return tuple(outs)
         ngm, qcm = _attn_plan(n, t, ATTN_CHUNK_BYTES)
         buf = torch.empty(ngm * qcm * t, device=q.device, dtype=torch.float32)
@@ -941,13 +944,18 @@ class _SelfAttention(torch.autograd.Function):
                     gemm_raw(_p(buf), _p(v, n0 * t * c), _p(o, (n0 * t + q0) * c), qc, c, t, (t, 1), (c, 1), (c, 1), ng,
                              (qc * t, t * c, t * c), tag="attn_pv")
         ctx.save_for_backward(q, *vs)
+        ctx.nv = -1
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gos):
-        q, *vs = ctx.saved_tensors
+        if ctx.nv > 0:
+            q, *rest = ctx.saved_tensors
+            vs, lse, fwd_outs = rest[:ctx.nv], rest[ctx.nv], rest[ctx.nv + 1:]
+        else:
+            q, *vs = ctx.saved_tensors
+            lse, fwd_outs = None, None
         n, t, d = q.shape
-        lse = getattr(ctx, "lse", None)
         csum = sum(v.shape[2] for v in vs)
         if lse is not None and FUSED_ATTENTION and (d, csum // 32) in ((64, 8), (32, 8), (32, 4), (64, 4)) and all(g is not None for g in gos):
             gos = [g.contiguous() for g in gos]
@@ -958,7 +966,7 @@ class _SelfAttention(torch.autograd.Function):
             c2 = vs[1].shape[2] if len(vs) > 1 else 0
             two = len(vs) > 1
             with _prof(f"attn_fused_bwd|T{t} d{d} C{c1 + c2} b{n}", 2.0 * n * t * t * (3 * d + 2 * (c1 + c2))):
-                _L().attention_bwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if two else None, _p(ctx.outs[0]), _p(ctx.outs[1]) if two else None,
+                _L().attention_bwd_f32(_p(q), _p(vs[0]), _p(vs[1]) if two else None, _p(fwd_outs[0]), _p(fwd_outs[1]) if two else None,
                                        _p(gos[0]), _p(gos[1]) if two else None, _p(lse), _p(delta), _p(gvs[0]), _p(gvs[1]) if two else None,
                                        _p(gq), n, t, d, c1, c2, _st())
             return (gq,) + tuple(gvs)
