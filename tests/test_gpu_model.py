@@ -344,3 +344,32 @@ def test_patch_discriminator_against_reference_golden(dev, golden):
             torch.testing.assert_close(sd1[k].cpu(), v, rtol=1e-5, atol=1e-6)
     with pytest.raises(NotImplementedError):
         network.define_d(model_type="nope")
+
+
+def test_training_steps_do_not_accumulate_device_tensors(dev, golden):
+    """every step must release the previous step's graph: the count of live device tensors is the same after step 3 and step 7
+    (a reference cycle node -> ctx attribute -> output tensor -> grad_fn once kept one discriminator graph alive per step)"""
+    import gc
+
+    from face_mask_inpaint_amd import functional as FF
+
+    fx = golden("picnet_train_tiny.pt")
+    G, D, gopt, _, _ = _tiny_models(fx, dev)
+    s = fx["step0"]
+    m = FF.binarise_mask(s["mask"].to(dev))
+    src, ref, gt = s["src"].to(dev), s["ref"].to(dev), s["gt"].to(dev)
+    eps = (s["eps_p"].to(dev), s["eps_q"].to(dev))
+
+    def live():
+        gc.collect()
+        return sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor) and o.is_cuda)
+
+    counts = []
+    for i in range(8):
+        gen = G(src, ref, src_mask=m, eps=eps)
+        out = gopt(D, src, gt, ref, gen, m)
+        del gen, out
+        if i in (3, 7):
+            torch.cuda.synchronize()
+            counts.append(live())
+    assert counts[1] <= counts[0] + 2, counts
