@@ -125,17 +125,18 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), batch_w, 1, (hipStream_t)stream);
 }
 
-extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
-                                    const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream) {
+static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias, const float* residual,
+                      const float* mask, float mslope, float* dx, int batch_w, int64_t w_bstride, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;  // reflect: run on the padded extent, then fmi_reflect_pad_fold_f32
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
+  if (mask && (bias || residual)) return FMI_ERR_UNSUPPORTED;  // the mask applies to the bare adjoint
 #ifndef FMI_HOST_EMU
-  if (batch_w == 1 && !bias && !residual && fmi_conv2d_thin_supported(d) && aligned16(dx))
+  if (batch_w == 1 && !bias && !residual && !mask && fmi_conv2d_thin_supported(d) && aligned16(dx))
     return fmi_conv2d_thin_dgrad_f32(d, dy, wt, dx, stream);
-  if (batch_w == 1 && !bias && !residual && d->C <= 4 && d->x_cstride == d->C) {  // thin INPUT: VGG16's first layer
+  if (batch_w == 1 && !bias && !residual && !mask && d->C <= 4 && d->x_cstride == d->C) {  // thin INPUT: VGG16's first layer
     const int rc_thin = fmi_conv2d_thin_input_dgrad_f32(d, dy, wt, dx, stream);
     if (rc_thin != FMI_ERR_UNSUPPORTED) return rc_thin;
   }
@@ -184,7 +185,9 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
       ConvWX lb{wt, g, w_bstride, d->C, (d->C % 4 == 0) && aligned16(wt) && (w_bstride % 4 == 0)};
       ConvEp ep{dx, bias, residual, GH, GW, s, py, px, d->H, d->W, d->x_cstride, 0, g.dGW, g.dG,
                 (int64_t)d->H * d->W * d->x_cstride};
-      ep.vec = !ep_scalar() && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual);
+      ep.vec = !ep_scalar() && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual) && aligned16(mask);
+      ep.mask = mask;
+      ep.mslope = mslope;
 #ifndef FMI_HOST_EMU
       if (strided_split) {
         ep.bias = nullptr;
@@ -232,6 +235,15 @@ extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
     }
   }
   return FMI_OK;
+}
+extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
+                                    const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream) {
+  return dgrad_impl(d, dy, wt, bias, residual, nullptr, 0.f, dx, batch_w, w_bstride, stream);
+}
+extern "C" int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope,
+                                           float* dx, void* stream) {
+  if (!mask) return FMI_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, wt, nullptr, nullptr, mask, mask_slope, dx, 1, 0, stream);
 }
 
 extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,

@@ -432,12 +432,21 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
   FastDiv dGW, dG;
   int64_t bs;
   int vec = 0;  // 16-byte epilogue allowed: N % 4 == 0, cstride % 4 == 0, y / res / bias 16-byte aligned, not the atomic mode
+  // adjoint of act(x) -> conv: the result is multiplied by act'(x) = (mask > 0 ? 1 : mslope), mask = x or act(x) in y's layout
+  // (LeakyReLU -> conv of the ResBlocks, ReLU -> conv inside VGG16): the separate activation-backward pass disappears
+  const float* mask = nullptr;
+  float mslope = 0.f;
   static constexpr bool HAS_VEC4 = true;
   __device__ void set_batch(int b) {
     y += (int64_t)b * bs;
     if (res) res += (int64_t)b * bs;
+    if (mask) mask += (int64_t)b * bs;
   }
   __device__ void store4(int64_t off, int col, float4 v) const {  // columns col .. col+3 of one row
+    if (mask) {
+      const float4 m4 = *reinterpret_cast<const float4*>(mask + off + col);
+      v.x *= m4.x > 0.f ? 1.f : mslope, v.y *= m4.y > 0.f ? 1.f : mslope, v.z *= m4.z > 0.f ? 1.f : mslope, v.w *= m4.w > 0.f ? 1.f : mslope;
+    }
     if (bias) {
       const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
       v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
@@ -458,6 +467,7 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
     return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
   }
   __device__ void store(int64_t off, int col, float v) const {
+    if (mask) v *= mask[off + col] > 0.f ? 1.f : mslope;  // linear: a split reduction masks every partial sum
     if (act == 3) {  // split reduction: y was initialised with bias + residual, the partial sums meet through fp32 atomics
       atomicAdd(y + off + col, v);
       return;

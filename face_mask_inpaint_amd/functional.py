@@ -244,17 +244,25 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, W) + bias + residual); x [N,H,W,C], wf [taps][C][K]."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act):
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False):
+        """in_act: None, ("apply", slope): the convolution reads lrelu(x, slope) (computed here, and only IT is kept for the backward),
+        ("mask", slope): x already is the output of such an activation; either way the input gradient is multiplied by act'(x) in the
+        adjoint's epilogue.  skip_act_bwd: this convolution's own fused activation (act) is differentiated by its single consumer (a
+        following convolution with in_act = ("mask", .)), not here."""
         _chk(x, wf, bias, residual)
         lib = _L()
+        if in_act is not None and in_act[0] == "apply":
+            x = eltwise(EW_LRELU, x, None, in_act[1])
         n, h, w, c = x.shape
         k = wf.shape[2]
         d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * n * oh * ow * k * c * kh * kw):
             lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
-        ctx.save_for_backward(x, wf, y if act else None)
+        ctx.save_for_backward(x, wf, y if (act and not skip_act_bwd) else None)
         ctx.wt, ctx.cfg, ctx.has = wt, (kh, kw, stride, pad, pad_mode, act), (bias is not None, residual is not None)
+        ctx.in_slope = None if in_act is None else float(in_act[1])
+        ctx.skip_act_bwd = bool(skip_act_bwd)
         return y
 
     @staticmethod
@@ -263,11 +271,12 @@ class _Conv2d(torch.autograd.Function):
         x, wf, y = ctx.saved_tensors
         kh, kw, stride, pad, pad_mode, act = ctx.cfg
         gy = gy.contiguous()
-        if act:
+        if act and not ctx.skip_act_bwd:
             gy = _act_bwd(gy, y, act)
         n, h, w, c = x.shape
         k = wf.shape[2]
         gx = gwf = gb = gres = None
+        masked = False
         if ctx.needs_input_grad[0]:
             d0, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
             if pad_mode == 1 and lib.conv2d_thin_supported(C.byref(d0)):  # thin output: adjoint and fold in one pass
@@ -286,7 +295,13 @@ class _Conv2d(torch.autograd.Function):
                 d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
-                    lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
+                    if ctx.in_slope is not None:  # act'(x) folded into the adjoint's epilogue
+                        lib.conv2d_dgrad_masked_f32(C.byref(d), _p(gy), _p(ctx.wt), _p(x), ctx.in_slope, _p(gx), _st())
+                        masked = True
+                    else:
+                        lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
+            if ctx.in_slope is not None and not masked:
+                gx = eltwise(EW_LRELU_BWD, gx, x, ctx.in_slope)
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
             gwf = _zeros_like(wf)
@@ -301,7 +316,7 @@ class _Conv2d(torch.autograd.Function):
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
-        return gx, gwf, gb, gres, None, None, None, None, None, None, None
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None
 
 
 class _ThinConvLReLU(torch.autograd.Function):
@@ -360,12 +375,12 @@ def lrelu_conv2d(x, pw: PackedWeight, bias=None, slope=0.1, pad=1, pad_mode=0, a
     return conv2d(leaky_relu(x, slope), pw, bias, None, 1, pad, pad_mode, act)
 
 
-def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE):
+def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, in_act=None, skip_act_bwd=False):
     if x.dtype == BF16:
-        if bias is not None or residual is not None or pad_mode or act:
+        if bias is not None or residual is not None or pad_mode or act or in_act is not None:
             raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding epilogue")
         return _Conv2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad)
-    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act)
+    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd)
 
 
 # ---- bf16 activations (StyleGAN2 decoder of configs C3 / C5): fp32 master weights, bf16 copies packed per call ----

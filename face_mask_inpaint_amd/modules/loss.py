@@ -57,11 +57,18 @@ class VGGLoss(torch.nn.Module):
             object.__setattr__(c, "_fmi_packed", pw)
 
     def _block(self, bi, x):
-        for m in self.blocks[bi]:
+        mods = [m for m in self.blocks[bi] if isinstance(m, (nn.MaxPool2d, nn.Conv2d))]
+        prev_conv = False
+        for i, m in enumerate(mods):
             if isinstance(m, nn.MaxPool2d):
                 x = FF.max_pool2(x)
-            elif isinstance(m, nn.Conv2d):
-                x = run_conv(m, x, act=FF.ACT_RELU)  # ReLU fused into the GEMM epilogue
+                prev_conv = False
+            else:
+                # ReLU fused into the GEMM epilogue.  Between two convolutions of a block the ReLU's backward runs in the NEXT
+                # convolution's adjoint epilogue (its input is this ReLU's output and it is the only consumer), not as a pass of its own
+                next_conv = i + 1 < len(mods) and isinstance(mods[i + 1], nn.Conv2d)
+                x = run_conv(m, x, act=FF.ACT_RELU, in_act=("mask", 0.0) if prev_conv else None, skip_act_bwd=next_conv)
+                prev_conv = True
         return x
 
     def _input(self, img):

@@ -152,14 +152,15 @@ class ResBlock(_NhwcBlock):
         with weight_scope(self):
             s = run_conv(_conv(self.bypass), x)
             if self._norms is None:
-                h = FF.leaky_relu(x, self._slope)
-                h = run_conv(_conv(self.conv1), h)
-                h = FF.leaky_relu(h, self._slope)
+                # LeakyReLU -> conv pairs: the activation is applied on the way in and differentiated in the adjoint's epilogue
+                act_in = ("apply", self._slope)
+                h = run_conv(_conv(self.conv1), x, in_act=act_in)
+                out = run_conv(_conv(self.conv2), h, residual=s, in_act=act_in)  # model(x) + shortcut(x), fused in the epilogue
             else:
                 h = _norm_act(self.model[0], x, self._slope)
                 h = run_conv(_conv(self.conv1), h)
                 h = _norm_act(self.model[3], h, self._slope)
-            out = run_conv(_conv(self.conv2), h, residual=s)  # model(x) + shortcut(x), fused in the epilogue
+                out = run_conv(_conv(self.conv2), h, residual=s)  # model(x) + shortcut(x), fused in the epilogue
             if self.sample:  # pool(a) + pool(b) == pool(a + b)
                 out = FF.avg_pool(out, 2)
             return out
@@ -181,8 +182,7 @@ class ResBlockEncoderOptimized(_NhwcBlock):
         with weight_scope(self):
             s = run_conv(_conv(self.bypass), FF.avg_pool(x, 2))
             h = run_conv(_conv(self.conv1), x)
-            h = FF.leaky_relu(h, self._slope)
-            h = run_conv(_conv(self.conv2), h)
+            h = run_conv(_conv(self.conv2), h, in_act=("apply", self._slope))
             return FF.add(FF.avg_pool(h, 2), s)
 
 
@@ -207,8 +207,7 @@ class ResBlockDecoder(_NhwcBlock):
         with weight_scope(self):
             s = run_conv(_conv(self.bypass), x)
             if self._norms is None:
-                h = FF.leaky_relu(x, self._slope)
-                h = run_conv(_conv(self.conv1), h)
+                h = run_conv(_conv(self.conv1), x, in_act=("apply", self._slope))
                 h = FF.leaky_relu(h, self._slope)
             else:
                 h = _norm_act(self.model[0], x, self._slope)

@@ -53,17 +53,22 @@ class SpectralNorm(nn.Module):
             return run_conv(self.module, x_nhwc, residual=residual, act=act, pad_mode=pad_mode, pad=pad)
 
 
-def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0, pad=None):
-    """Run a (prepared) nn.Conv2d / nn.ConvTranspose2d parameter holder on an NHWC tensor."""
+def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0, pad=None, in_act=None, skip_act_bwd=False):
+    """Run a (prepared) nn.Conv2d / nn.ConvTranspose2d parameter holder on an NHWC tensor.  ``in_act`` = ("apply", slope): the
+    convolution reads lrelu(x, slope); ("mask", slope): x already is that activation's output -- see functional._Conv2d."""
     pw = packed(conv)
     if isinstance(conv, nn.ConvTranspose2d):
         if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1:
             raise NotImplementedError("ConvTranspose2d geometry outside the hot path")
+        if in_act is not None:
+            if in_act[0] != "apply":
+                raise NotImplementedError("ConvTranspose2d with a masked input gradient")
+            x_nhwc = FF.leaky_relu(x_nhwc, in_act[1])
         return FF.conv_transpose2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], conv.padding[0], conv.output_padding[0])
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1 or conv.dilation != (1, 1):
         raise NotImplementedError("Conv2d geometry outside the hot path")
     p = conv.padding[0] if pad is None else pad
-    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act)
+    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act, in_act, skip_act_bwd)
 
 
 class GANLoss(nn.Module):

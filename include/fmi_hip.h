@@ -86,6 +86,12 @@ int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, 
  * fmi_reflect_pad_fold_f32). */
 int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
                          const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream);
+/* Adjoint of  act(x) -> conv : dx = conv_adjoint(dy, wt) * act'(x), act' = (mask > 0 ? 1 : mask_slope); mask = x or act(x), dx's layout.
+ * The LeakyReLU -> conv pairs of ResBlock / ResBlockEncoderOptimized (base_function.py:207-305) and the ReLU -> conv pairs inside
+ * VGG16 (loss.py:45-65): the multiplication happens in the GEMM epilogue, the separate activation-backward pass disappears.
+ * Zero padding, shared weights, no bias / residual. */
+int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope, float* dx,
+                                void* stream);
 /* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf.
  * dbias (may be NULL; needs kh*kw*C % 4 == 0 and batch_w == 1): dbias[k] += sum over pixels dy[p][k], computed by the same
  * GEMM as one extra row of ones -- no separate pass over dy; caller zeroes it. */

@@ -525,6 +525,37 @@ def test_thin_output_conv(dev, FF, n, c, k, h, w, pad_mode, act):
         torch.testing.assert_close(dx2.cpu(), nhwc(x.grad), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,slope", [(2, 32, 64, 33, 31, 3, 1, 0.1), (2, 128, 128, 16, 16, 3, 1, 0.1), (1, 16, 48, 20, 20, 1, 1, 0.2),
+                                                         (2, 32, 64, 32, 32, 3, 2, 0.1), (2, 64, 64, 24, 24, 3, 1, 0.0), (4, 128, 128, 8, 8, 3, 1, 0.1)])
+def test_conv_with_input_activation(dev, FF, n, c, k, h, w, ksz, stride, slope):
+    """FF.conv2d(in_act=("apply", s)) = conv(lrelu(x, s)) and in_act=("mask", s) on an already activated input: values and gradients
+    against autograd; the input gradient is produced by fmi_conv2d_dgrad_masked_f32 (activation derivative in the adjoint's epilogue,
+    also when the reduction is split over workgroups)"""
+    from face_mask_inpaint_amd.functional import PackedWeight
+
+    g = torch.Generator().manual_seed(h * 11 + c + k)
+    x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
+    wt_ = (torch.randn(k, c, ksz, ksz, generator=g) / (c * ksz * ksz) ** 0.5).requires_grad_(True)
+    b = torch.randn(k, generator=g, requires_grad=True)
+    pad = ksz // 2
+    a = F.leaky_relu(x, slope)
+    y = F.conv2d(a, wt_, b, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    wf, wtp = [t.to(dev) for t in pack(wt_.detach())]
+    for mode in ("apply", "mask"):
+        wfd = wf.clone().requires_grad_(True)
+        xin = nhwc(x.detach() if mode == "apply" else a.detach()).to(dev).requires_grad_(True)
+        bd = b.detach().to(dev).requires_grad_(True)
+        out = FF.conv2d(xin, PackedWeight(wfd, wtp, k, c, ksz, ksz), bd, None, stride, pad, 0, FF.ACT_NONE, (mode, slope))
+        torch.testing.assert_close(out.detach().cpu(), nhwc(y.detach()), rtol=1e-4, atol=1e-5)
+        out.backward(nhwc(gy).to(dev))
+        torch.testing.assert_close(xin.grad.cpu(), nhwc(x.grad), rtol=1e-4, atol=1e-5)
+        tol = 2e-4 * max(1.0, (n * y.shape[2] * y.shape[3] / 2048.0) ** 0.5)
+        torch.testing.assert_close(wfd.grad.cpu(), pack(wt_.grad)[0], rtol=1e-4, atol=tol)
+        torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=tol)
+
+
 @pytest.mark.parametrize("n,c,k,h,w,pad_mode", [(2, 32, 3, 20, 24, 1), (1, 32, 3, 70, 33, 1), (2, 32, 4, 9, 12, 0), (1, 16, 3, 12, 12, 1)])
 def test_output_block_fused_lrelu_conv_tanh(dev, FF, n, c, k, h, w, pad_mode):
     """FF.lrelu_conv2d = tanh(conv3x3(pad(lrelu(x)))) (base_function.py:386-396) with the LeakyReLU folded into the thin-output
