@@ -61,11 +61,18 @@ static int conv_ksplit(int64_t M, int N, int K) {
   // keep the 128-wide tiles (operand reuse) and fill the chip by splitting the reduction instead of shrinking the tile
   const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128));
   if (K < 512) return 1;
+  static const int ks_dbg = getenv("FMI_KS") ? atoi(getenv("FMI_KS")) : 0;  // experiment: force the split
+  if (ks_dbg > 0) return ks_dbg;
   if (tiles >= 320) {
     // between one and two "waves" of workgroups (3 per CU x 256 CUs) the CUs that got 3 tiles set the time while the others idle
-    // (VGG 28^2: 588 tiles = 2.3 per CU): halving the work unit lets the dispatcher even it out
-    return tiles < 1200 && K >= 2304 ? 3 : 1;
+    // (VGG 28^2: 588 tiles = 2.3 per CU): splitting the work unit lets the dispatcher even it out.  Measured (TFLOP/s, split 1 / 2 / 3):
+    // 588 tiles K 4608: 102 / 111 / 118;  588 tiles K 2304: 101 / 107 / 109;  512 tiles K 2304: 111 / 116 / 111;
+    // 1024 tiles K 2304: 125 / 118 / 114;  1176 tiles K 2304: 101 / 97 / 100  ->  no split from ~800 tiles up
+    if (tiles >= 800 || K < 2304) return 1;
+    return tiles <= 520 ? 2 : 3;
   }
+  // 192 .. 319 tiles with a short reduction (8 x 64^2 128 -> 128: 256 tiles, 72 k-tiles): 92 TFLOP/s unsplit, 81 split in two
+  if (tiles >= 192 && K < 2304) return 1;
   int64_t ks = ceil_div64(384, tiles);
   // at least 16 k-tiles per split; a handful of output tiles (M <= 128 rows: the pSp style heads at 4^2 .. 1^2) only stream the
   // weights, so more, shorter splits put more loads in flight: 4 k-tiles there
