@@ -26,7 +26,6 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round to nearest even (i
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 static bool aligned16b(const void* p) { return ((uintptr_t)p & 15) == 0; }
 

@@ -10,9 +10,6 @@
 
 #ifndef FMI_HOST_EMU
 typedef uint16_t bf16_t;
-struct bf8 {
-  uint4 v;
-};
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf(float a, float b) {  // round to nearest even
