@@ -71,8 +71,9 @@ static int conv_ksplit(int64_t M, int N, int K) {
     if (tiles >= 800 || K < 2304) return 1;
     return tiles <= 520 ? 2 : 3;
   }
-  // 192 .. 319 tiles with a short reduction (8 x 64^2 128 -> 128: 256 tiles, 72 k-tiles): 92 TFLOP/s unsplit, 81 split in two
-  if (tiles >= 192 && K < 2304) return 1;
+  // 192 .. 319 tiles: unsplit wins up to K = 2304 (256 tiles: 8 x 64^2 128 -> 128 92 vs 81 TFLOP/s split in two; the IR-SE50 stage
+  // 16 x 32^2 256 -> 256 94.5 vs 89)
+  if (tiles >= 192 && K < 4608) return 1;
   int64_t ks = ceil_div64(384, tiles);
   // at least 16 k-tiles per split; a handful of output tiles (M <= 128 rows: the pSp style heads at 4^2 .. 1^2) only stream the
   // weights, so more, shorter splits put more loads in flight: 4 k-tiles there

@@ -3,5 +3,5 @@ import sys
 sys.path.insert(0, "/root/repo")
 sys.argv = [sys.argv[0], "none"]
 import scripts.microbench as mb
-for (n, h, c, k) in [(24, 56, 256, 256), (24, 28, 256, 512), (24, 28, 512, 512), (8, 128, 256, 128), (8, 64, 256, 256), (24, 112, 128, 128)]:
+for (n, h, c, k) in [(16, 32, 256, 256), (16, 64, 128, 128), (16, 16, 512, 512), (16, 128, 64, 64)]:
     mb.conv_case(n, h, c, k)
