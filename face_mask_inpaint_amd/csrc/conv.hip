@@ -280,6 +280,8 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
   const int64_t kmax = Kg / 512;
   if (ksplit > kmax) ksplit = kmax;
   if (ksplit < 1) ksplit = 1;
+  static const int wks_dbg = getenv("FMI_WKS") ? atoi(getenv("FMI_WKS")) : 0;  // experiment: force the pixel split of the weight gradient
+  if (wks_dbg > 0) ksplit = wks_dbg;
   if (ksplit * batch_w > 65535) ksplit = 65535 / batch_w;
   return launch_gemm(la, lb, ep, Mg, Ng, Kg, batch_w, (int)ksplit, (hipStream_t)stream);
 }
