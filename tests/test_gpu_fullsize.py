@@ -1,0 +1,126 @@
+"""Parity at BASELINE.json's FULL sizes (configs[1]: 256x256 inputs, bs 8 -> decoder maps up to 8 x 1024 x 1024 x 32, 16384 attention
+tokens) through size-independent properties, where a CPU oracle run would take minutes:
+
+  * adjointness  <A x, y> = <x, A^T y>  ties the forward kernel to the input-gradient kernel, and  <conv(x; w), y> = <w, dW(x, y)>
+    ties it to the weight-gradient kernel -- three independently written kernels (different loaders / tilings / split rules) must agree
+    on one bilinear form, which catches indexing or 32-bit overflow errors that only appear at scale;
+  * softmax rows sum to one: attention of a constant value map is that constant; attention is linear in the values; the value
+    gradient of an all-ones cotangent sums to T per channel;
+  * a normalised blur preserves constants away from the border.
+fp32 tolerances are relative to the magnitude of the bilinear form's terms (sums of ~1e9 products of O(1) values)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def FF():
+    from face_mask_inpaint_amd import functional
+
+    return functional
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _pw(FF, w):
+    """w [K, C, kh, kw] -> PackedWeight with a differentiable wf"""
+    k, c, kh, kw = w.shape
+    wf = w.permute(2, 3, 1, 0).reshape(kh * kw, c, k).contiguous().requires_grad_(True)
+    wt = w.permute(2, 3, 0, 1).reshape(kh * kw, k, c).contiguous()
+    return FF.PackedWeight(wf, wt, k, c, kh, kw), wf
+
+
+@pytest.mark.parametrize("n,h,c,k,stride", [(8, 1024, 32, 32, 1), (8, 512, 64, 32, 1), (8, 256, 128, 64, 1), (8, 256, 64, 128, 2), (24, 224, 64, 64, 1)])
+def test_conv_adjointness_full_size(dev, FF, n, h, c, k, stride):
+    g = torch.Generator(device="cpu").manual_seed(h + c)
+    x = torch.randn(n, h, h, c, device=dev, requires_grad=True)
+    w = torch.randn(k, c, 3, 3, generator=g).to(dev) / (9 * c) ** 0.5
+    pw, wf = _pw(FF, w)
+    y = FF.conv2d(x, pw, None, None, stride, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    lhs = _dot(y.detach(), gy)
+    scale = float(y.detach().norm()) * float(gy.norm())
+    assert abs(lhs - _dot(x.detach(), x.grad)) <= 2e-5 * scale      # forward vs input-gradient kernel
+    assert abs(lhs - _dot(wf.detach(), wf.grad)) <= 2e-5 * scale    # forward vs weight-gradient kernel
+
+
+@pytest.mark.parametrize("n,h,cs,cb", [(8, 512, 64, 32), (8, 128, 256, 128), (8, 512, 32, 32)])
+def test_conv_transpose_adjointness_full_size(dev, FF, n, h, cs, cb):
+    """ConvTranspose2d(3, stride 2, pad 1, out_pad 1) of the decoder (base_function.py:308-364) at its largest shapes"""
+    g = torch.Generator(device="cpu").manual_seed(h + cs)
+    x = torch.randn(n, h, h, cs, device=dev, requires_grad=True)
+    w = torch.randn(cs, cb, 3, 3, generator=g).to(dev) / (9 * cs) ** 0.5   # conv view: rows = Cs, C = Cb
+    pw, wf = _pw(FF, w)
+    y = FF.conv_transpose2d(x, pw, None, None, 2, 1, 1)
+    assert y.shape == (n, 2 * h, 2 * h, cb)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    lhs = _dot(y.detach(), gy)
+    scale = float(y.detach().norm()) * float(gy.norm())
+    assert abs(lhs - _dot(x.detach(), x.grad)) <= 2e-5 * scale
+    assert abs(lhs - _dot(wf.detach(), wf.grad)) <= 2e-5 * scale
+
+
+def test_attention_properties_full_size(dev, FF):
+    """Auto_Attn of the decoder: 16384 tokens, d 64, C 256 (base_function.py:401-448), batch 2"""
+    n, t, d, c = 2, 16384, 64, 256
+    q = torch.randn(n, t, d, device=dev) * 0.3
+    ones = torch.ones(n, t, c, device=dev)
+    (o,) = FF.self_attention(q, [ones])
+    assert float((o - 1).abs().max()) < 1e-5                                   # rows of softmax sum to one
+    v1, v2 = torch.randn(n, t, c, device=dev), torch.randn(n, t, c, device=dev)
+    (o1,), (o2,), (o12,) = FF.self_attention(q, [v1]), FF.self_attention(q, [v2]), FF.self_attention(q, [v1 + 2 * v2])
+    assert float((o12 - (o1 + 2 * o2)).abs().max()) < 2e-4                     # linear in the values (fp32 sums over 16384 keys)
+    v = v1.clone().requires_grad_(True)
+    qg = q.clone().requires_grad_(True)
+    (o,) = FF.self_attention(qg, [v])
+    o.backward(torch.ones_like(o))
+    colsum = v.grad.sum(dim=1)                                                 # sum over keys of sum_q P[q][key] = T, per channel
+    assert float((colsum / t - 1).abs().max()) < 1e-5
+    # d/dq of sum(o) with o = P v: adjointness with the value path: <o, 1> = <v, dV>
+    assert abs(_dot(o.detach(), torch.ones_like(o)) - _dot(v.detach(), v.grad)) <= 2e-5 * float(o.detach().norm()) * (n * t * c) ** 0.5
+    assert torch.isfinite(qg.grad).all()
+
+
+@pytest.mark.parametrize("n,h,c,k", [(16, 256, 128, 128), (16, 64, 512, 512)])
+def test_bf16_conv_adjointness_decoder_size(dev, FF, n, h, c, k):
+    """bf16 convolution family at the StyleGAN2 decoder's largest layers: every tensor is rounded to bf16 once on store, so the
+    bilinear forms agree to bf16 rounding of their O(sqrt(count)) accumulated noise"""
+    g = torch.Generator(device="cpu").manual_seed(h + c)
+    x = torch.randn(n, h, h, c, device=dev).bfloat16().requires_grad_(True)
+    w = torch.randn(k, c, 3, 3, generator=g).to(dev) / (9 * c) ** 0.5
+    pw, wf = _pw(FF, w)
+    y = FF.conv2d(x, pw, None, None, 1, 1)
+    gy = torch.randn(y.shape, device=dev).bfloat16()
+    y.backward(gy)
+    lhs = _dot(y.detach(), gy)
+    scale = float(y.detach().float().norm()) * float(gy.float().norm())
+    assert abs(lhs - _dot(x.detach(), x.grad)) <= 1e-3 * scale
+    assert abs(lhs - _dot(wf.detach(), wf.grad)) <= 1e-3 * scale
+
+
+def test_blur_preserves_constants_full_size(dev):
+    """the native upfirdn2d op on the Blur shape of the 1024^2 decoder: 32 planes 1025^2 -> 1024^2, [1,3,3,1] x [1,3,3,1] / 64"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.op.upfirdn2d import _native
+
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k = (k[None, :] * k[:, None] / 64).to(dev)
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        x = torch.full((32, 1025, 1025), 1.5, device=dev).to(dt)
+        y = _native(x, k, 1, 1, 1, 1, 1, 1, 1, 1)
+        assert y.shape == (32, 1024, 1024)
+        assert float((y[:, 2:-2, 2:-2].float() - 1.5).abs().max()) <= tol
+        r = torch.randn(32, 1025, 1025, device=dev).to(dt)
+        yr = _native(r, k, 1, 1, 1, 1, 1, 1, 1, 1)
+        # interior sum is preserved up to the border rows / columns (the kernel sums to one)
+        assert abs(float(yr.float().sum()) - float(r.float().sum())) <= 5e-3 * float(r.float().abs().sum())
