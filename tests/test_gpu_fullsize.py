@@ -124,3 +124,41 @@ def test_blur_preserves_constants_full_size(dev):
         yr = _native(r, k, 1, 1, 1, 1, 1, 1, 1, 1)
         # interior sum is preserved up to the border rows / columns (the kernel sums to one)
         assert abs(float(yr.float().sum()) - float(r.float().sum())) <= 5e-3 * float(r.float().abs().sum())
+
+
+def test_thin_output_conv_adjointness_full_size(dev, FF):
+    """the generator's Output convolution (32 -> 3, reflection padding, base_function.py:386-396) on 8 x 1024 x 1024: its three
+    dedicated kernels (LDS-halo forward, MFMA adjoint with the reflect fold, persistent weight gradient) against one another"""
+    n, h, c, k = 8, 1024, 32, 3
+    x = torch.randn(n, h, h, c, device=dev, requires_grad=True)
+    w = torch.randn(k, c, 3, 3, device=dev) / (9 * c) ** 0.5
+    pw, wf = _pw(FF, w)
+    b = torch.zeros(k, device=dev, requires_grad=True)
+    y = FF.conv2d(x, pw, b, None, 1, 1, 1)  # pad_mode = reflect
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    lhs = _dot(y.detach(), gy)
+    scale = float(y.detach().norm()) * float(gy.norm())
+    assert abs(lhs - _dot(x.detach(), x.grad)) <= 2e-5 * scale
+    assert abs(lhs - _dot(wf.detach(), wf.grad)) <= 2e-5 * scale
+    assert abs(float(b.grad.double().sum()) - float(gy.double().sum())) <= 1e-5 * float(gy.abs().sum())
+
+
+def test_instance_norm_statistics_full_size(dev, FF):
+    """InstanceNorm2d(affine) + LeakyReLU(slope 1 = off) on the decoder's largest normalised map 8 x 512 x 512 x 64: per (sample, channel)
+    the output has mean beta and standard deviation gamma; its input gradient is orthogonal to constants and to x-hat"""
+    n, h, c = 8, 512, 64
+    x = (torch.randn(n, h, h, c, device=dev) * 3 + 5).requires_grad_(True)
+    gamma = (torch.rand(c, device=dev) + 0.5).requires_grad_(True)
+    beta = torch.randn(c, device=dev).requires_grad_(True)
+    y = FF.instance_norm_act(x, gamma, beta, 1e-5, 1.0)
+    m = y.detach().double().mean(dim=(1, 2))
+    s = y.detach().double().std(dim=(1, 2), unbiased=False)
+    assert float((m - beta.detach().double()).abs().max()) < 1e-4
+    assert float((s / gamma.detach().double() - 1).abs().max()) < 1e-4
+    g = torch.randn_like(y)
+    y.backward(g)
+    gx = x.grad.double()
+    assert float(gx.sum(dim=(1, 2)).abs().max()) < 1e-2 * float(gx.abs().sum(dim=(1, 2)).max()) * 1e-2   # sum over the plane vanishes
+    xh = (x.detach().double() - x.detach().double().mean(dim=(1, 2), keepdim=True))
+    assert float((gx * xh).sum(dim=(1, 2)).abs().max()) < 1e-4 * float((gx.abs() * xh.abs()).sum(dim=(1, 2)).max())
