@@ -162,3 +162,27 @@ def test_instance_norm_statistics_full_size(dev, FF):
     assert float(gx.sum(dim=(1, 2)).abs().max()) < 1e-2 * float(gx.abs().sum(dim=(1, 2)).max()) * 1e-2   # sum over the plane vanishes
     xh = (x.detach().double() - x.detach().double().mean(dim=(1, 2), keepdim=True))
     assert float((gx * xh).sum(dim=(1, 2)).abs().max()) < 1e-4 * float((gx.abs() * xh.abs()).sum(dim=(1, 2)).max())
+
+
+def test_bf16_decoder_1024_tracks_fp32(dev):
+    """BASELINE.json configs[4]: the 1024^2 StyleGAN2 decoder (18 styles, 32- and 64-channel layers at 512^2 / 1024^2 -> the BK = 32
+    convolution tiles, the 128x32 output tiles, ToRGB at 1024^2) in bf16 against the fp32 decoder on the same parameters and noise"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator
+
+    torch.manual_seed(0)
+    g32 = Generator(1024, 512, 2).to(dev)
+    g16 = Generator(1024, 512, 2, compute_dtype=torch.bfloat16).to(dev)
+    g16.load_state_dict(g32.state_dict())
+    lat = torch.randn(1, g32.n_latent, 512, device=dev)
+    imgs = []
+    for gen in (g32, g16):
+        img, _ = gen([lat], input_is_latent=True, randomize_noise=False)
+        assert img.shape == (1, 3, 1024, 1024) and img.dtype == torch.float32
+        (img ** 2).mean().backward()
+        assert all(torch.isfinite(p.grad).all() for p in gen.parameters() if p.grad is not None)
+        imgs.append(img.detach())
+    rel = float((imgs[0] - imgs[1]).abs().max()) / float(imgs[0].abs().max())
+    assert rel < 5e-2, rel
+    n32 = torch.cat([p.grad.flatten() for p in g32.convs.parameters() if p.grad is not None])
+    n16 = torch.cat([p.grad.flatten() for p in g16.convs.parameters() if p.grad is not None])
+    assert float((n32 - n16).norm()) < 8e-2 * float(n32.norm())
