@@ -171,10 +171,12 @@ struct __attribute__((packed, aligned(4))) uf_h8 {
 template <class T, int KH, int KW>
 __global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict__ in, const T* __restrict__ kernel, T* __restrict__ out,
                                                              UfParams p) {
-  constexpr int IH = FW_TH + KH - 1, IW = FW_TW + KW - 1, LDW = IW + 2;
+  constexpr int IH = FW_TH + KH - 1, IW = FW_TW + KW - 1;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int EV = BF ? 8 : 4;  // elements per 16-byte load
-  __shared__ float sx[IH * LDW];
+  constexpr int VPR = (IW + (BF ? 1 : 0) + EV - 1) / EV;  // 16-byte vectors per window row
+  constexpr int LDW = VPR * EV;  // LDS row pitch: whole vectors, so every staged vector is stored with 16-byte ds_write_b128
+  __shared__ __attribute__((aligned(16))) float sx[IH * LDW];
   float kf[KH][KW];
 #pragma unroll
   for (int a = 0; a < KH; ++a)
@@ -192,12 +194,14 @@ __global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict
   const int64_t pend = (int64_t)p.major * p.in_h * p.in_w; // one past the last element of the tensor
   // staging: row ry of the window = elements [rowE, rowE + IW) of the flat tensor (where inside the image); vector j of that row
   // starts at the EV-aligned-to-word element (rowE & ~(BF ? 1 : 0)) + EV * j
-  constexpr int VPR = (IW + (BF ? 1 : 0) + EV - 1) / EV;  // vectors per row
-  for (int t = tid; t < IH * VPR; t += 256) {
-    const int ry = t / VPR, j = t - ry * VPR;
+  // bf16: a window row is staged by one 32-lane half of a wave, so that the realigning shuffle below stays inside the row
+  constexpr int LPR = BF ? 32 : VPR;
+  static_assert(VPR <= LPR, "lanes per staged row");
+  for (int t = tid; t < IH * LPR; t += 256) {
+    const int ry = t / LPR, j = t - ry * LPR;
     const int iy = iy0 + ry;
     float* dst = sx + ry * LDW;
-    const bool rowok = (unsigned)iy < (unsigned)p.in_h;
+    const bool rowok = (unsigned)iy < (unsigned)p.in_h && j < VPR;
     const int64_t rowE = pbase + (int64_t)iy * p.in_w + ix0;        // element of window column 0 (may lie outside the row)
     const int sh = BF ? (int)(rowE & 1) : 0;                         // bf16: loads start on a 4-byte word
     const int64_t e0 = rowE - sh + (int64_t)EV * j;                  // first element of this vector
@@ -219,11 +223,26 @@ __global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict
       for (int e = 0; e < EV; ++e)
         if (e0 + e >= 0 && e0 + e < pend) f[e] = uf_ld(in, e0 + e);
     }
+    if constexpr (BF) {
+      // rows whose first element is odd were loaded from one element earlier (word alignment): shift them left by one so that LDS
+      // column = window column for every row (the vector of the next lane supplies the last element; at a row's last vector that
+      // element lies beyond the window)
+      const float nxt = __shfl_down(f[0], 1, 64);
+      if (sh) {
+#pragma unroll
+        for (int e = 0; e < EV - 1; ++e) f[e] = f[e + 1];
+        f[EV - 1] = nxt;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < EV; ++e) {
-      const int rx = EV * j + e - sh;  // window column
-      const int ix = ix0 + rx;
-      if (rx >= 0 && rx < IW) dst[rx] = (rowok && (unsigned)ix < (unsigned)p.in_w) ? f[e] : 0.f;
+      const int ix = ix0 + EV * j + e;  // image column of this element
+      if (!rowok || (unsigned)ix >= (unsigned)p.in_w) f[e] = 0.f;
+    }
+    if (j < VPR) {
+      float4* d4 = reinterpret_cast<float4*>(dst + EV * j);
+      d4[0] = make_float4(f[0], f[1], f[2], f[3]);
+      if constexpr (BF) d4[1] = make_float4(f[4], f[5], f[6], f[7]);
     }
   }
   __syncthreads();
@@ -237,9 +256,12 @@ __global__ void __launch_bounds__(256) upfirdn2d_firw_kernel(const T* __restrict
     for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
 #pragma unroll
   for (int r = 0; r < 4 + KH - 1; ++r) {
-    float v[KW + 3];
-#pragma unroll
-    for (int b = 0; b < KW + 3; ++b) v[b] = sx[(ly0 + r) * LDW + lx + b];
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(sx + (ly0 + r) * LDW + lx);
+      const float4 hi = *reinterpret_cast<const float4*>(sx + (ly0 + r) * LDW + lx + 4);
+      v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+    }
 #pragma unroll
     for (int a = 0; a < KH; ++a) {
       const int o = r - a;
