@@ -1460,6 +1460,7 @@ class _BatchNormTrain(torch.autograd.Function):
         lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), 1, rows, c, 1.0, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output (one fill launch per BatchNorm and step)
         return y, stats
 
     @staticmethod
