@@ -98,16 +98,16 @@ def native_op_bandwidth(dev):
         res = {}
         for key, fn, nbytes in (("upfirdn2d", lambda: _native(x, k, 1, 1, 1, 1, 1, 1, 1, 1), (128 * 1025 * 1025 + 128 * 1024 * 1024) * x.element_size()),
                                 ("fused_bias_act", lambda: fused_bias_act(a, b, empty, 3, 0, 0.2, 2 ** 0.5), 2 * a.numel() * a.element_size())):
-            for _ in range(2):
+            for _ in range(5):
                 fn()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             s.record()
-            for _ in range(5):
+            for _ in range(30):
                 fn()
             e.record()
             torch.cuda.synchronize()
-            ms = s.elapsed_time(e) / 5
+            ms = s.elapsed_time(e) / 30
             res[key] = {"ms": round(ms, 3), "GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
         out[name] = res
     return out
