@@ -84,7 +84,7 @@ SIGNATURES = {
     "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "fmi_instnorm_stats_f32": [vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
-    "fmi_batchnorm_running_update_f32": [vp, vp, vp, vp, i32, i64, f32, f32, vp],
+    "fmi_batchnorm_running_update_f32": [vp, vp, vp, vp, vp, i32, i64, f32, f32, vp],
     "fmi_instnorm_apply_f32": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_instnorm_bwd_reduce_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
     "fmi_instnorm_bwd_apply_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
@@ -113,6 +113,7 @@ SIGNATURES = {
     "fmi_prelu_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "fmi_subsample_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_bias_grad_nchw_f32": [vp, i32, i32, i64, vp, vp],
+    "fmi_bias_grad_nchw_bf16": [vp, i32, i32, i64, vp, vp],
     "fmi_noise_bias_act_f32": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
 }
 

@@ -363,21 +363,32 @@ extern "C" int fmi_noise_bias_act_f32(const float* x, const float* bias, const f
 }
 
 // dbias[c] += sum over (n, hw) of g[n][c][hw]   (NCHW; grad_bias of FusedLeakyReLU, op/fused_act.py:29-36)
-__global__ void __launch_bounds__(256) bias_grad_nchw_kernel(const float* __restrict__ g, int N, int C, int64_t HW,
+__device__ __forceinline__ float bg_load(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float bg_load(const uint16_t* p, int64_t i) { return __uint_as_float((uint32_t)p[i] << 16); }
+template <typename T>
+__global__ void __launch_bounds__(256) bias_grad_nchw_kernel(const T* __restrict__ g, int N, int C, int64_t HW,
                                                              float* __restrict__ dbias) {
   __shared__ float red[4];
   const int c = blockIdx.x % C, n = blockIdx.x / C;
-  const float* p = g + ((int64_t)n * C + c) * HW;
+  const T* p = g + ((int64_t)n * C + c) * HW;
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.y * 256) s += p[i];
+  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.y * 256) s += bg_load(p, i);
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) atomicAdd(dbias + c, s);
 }
-extern "C" int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream) {
+template <typename T>
+static int bias_grad_nchw_launch(const T* g, int N, int C, int64_t HW, float* dbias, void* stream) {
   if (!g || !dbias || N <= 0 || C <= 0 || HW <= 0 || (int64_t)N * C > 0x7fffffffLL) return FMI_ERR_BAD_ARG;
   int gy = (int)((HW + 256 * 16 - 1) / (256 * 16));
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
-  hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(N * C, gy), dim3(256), 0, (hipStream_t)stream, g, N, C, HW, dbias);
+  hipLaunchKernelGGL(bias_grad_nchw_kernel<T>, dim3(N * C, gy), dim3(256), 0, (hipStream_t)stream, g, N, C, HW, dbias);
   return fmi_launch_status();
+}
+extern "C" int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream) {
+  return bias_grad_nchw_launch(g, N, C, HW, dbias, stream);
+}
+// bf16 cotangent (fused_leaky_relu on a bf16 tensor), fp32 sums
+extern "C" int fmi_bias_grad_nchw_bf16(const void* g, int N, int C, int64_t HW, float* dbias, void* stream) {
+  return bias_grad_nchw_launch((const uint16_t*)g, N, C, HW, dbias, stream);
 }

@@ -991,7 +991,7 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
   if (const char* r = getenv("FMI_DMA_OFF_RANGE")) {  // debug: "a:b" = launches a <= i < b of this process use the register-staged kernel
     long a = 0, b = 0;
     sscanf(r, "%ld:%ld", &a, &b);
-    const long i = fmi_debug_launch_counter++;
+    const long i = __atomic_fetch_add(&fmi_debug_launch_counter, 1L, __ATOMIC_RELAXED);  // forward and autograd threads both launch
     if (i >= a && i < b) dma = false;
     if (getenv("FMI_DMA_TRACE")) fprintf(stderr, "[fmi launch %ld] family %d M %d N %d K %d batch %d ksplit %d dma %d (eligible %d %d)\n", i, family, M, N, K, batch, ksplit, (int)dma, (int)la.dma_ok(), (int)lb.dma_ok());
   }

@@ -10,5 +10,6 @@ extern "C" const char* fmi_status_string(int status) {
 }
 extern "C" int fmi_version(void) { return 1; }
 
-// debug launch counter of the GEMM-family launcher (gemm_core.h: FMI_DMA_OFF_RANGE)
+// debug launch counter of the GEMM-family launcher (gemm_core.h: FMI_DMA_OFF_RANGE); touched only when that variable is set,
+// and then with an atomic increment -- the library has no other mutable global
 extern "C" long fmi_debug_launch_counter = 0;

@@ -279,22 +279,31 @@ extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const
 // nn.BatchNorm2d running-statistics bookkeeping (torch/nn/modules/batchnorm.py semantics: momentum average of the batch mean and of
 // the UNBIASED batch variance, num_batches_tracked += 1) from the (mean, rstd) pairs the statistics pass produced: one launch per
 // BatchNorm instead of nine [C]-sized ATen kernels (104 BatchNorms per pSp step).
-__global__ void __launch_bounds__(256) bn_running_update_kernel(const float* __restrict__ stats, float* __restrict__ rmean,
-                                                                float* __restrict__ rvar, int64_t* __restrict__ nbt, int C, float unbias,
-                                                                float eps, float momentum) {
+__global__ void __launch_bounds__(256) bn_running_update_kernel(const float* __restrict__ stats, const double* __restrict__ sums,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                int64_t* __restrict__ nbt, int C, float unbias, double count, float eps,
+                                                                float momentum) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0 && nbt) nbt[0] += 1;
   if (c >= C) return;
   const float mean = stats[2 * c], rstd = stats[2 * c + 1];
-  const float var = (1.f / (rstd * rstd) - eps) * unbias;
+  float var;
+  if (sums) {  // the fp64 (sum, sum of squares) of the statistics pass: no 1 / rstd^2 - eps cancellation when var << eps
+    const double m = sums[2 * c] / count;
+    double v = sums[2 * c + 1] / count - m * m;
+    var = (float)((v < 0 ? 0 : v) * (double)unbias);
+  } else {
+    var = fmaxf(1.f / (rstd * rstd) - eps, 0.f) * unbias;
+  }
   rmean[c] = __fadd_rn(__fmul_rn(rmean[c], 1.f - momentum), __fmul_rn(momentum, mean));
   rvar[c] = __fadd_rn(__fmul_rn(rvar[c], 1.f - momentum), __fmul_rn(momentum, var));
 }
-extern "C" int fmi_batchnorm_running_update_f32(const float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                                                int C, int64_t count, float eps, float momentum, void* stream) {
+extern "C" int fmi_batchnorm_running_update_f32(const float* stats, const double* sums, float* running_mean, float* running_var,
+                                                int64_t* num_batches_tracked, int C, int64_t count, float eps, float momentum,
+                                                void* stream) {
   if (!stats || !running_mean || !running_var || C <= 0 || count <= 0) return FMI_ERR_BAD_ARG;
   const float unbias = (float)((double)count / (double)(count > 1 ? count - 1 : 1));
-  hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, running_mean, running_var,
-                     num_batches_tracked, C, unbias, eps, momentum);
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, sums, running_mean, running_var,
+                     num_batches_tracked, C, unbias, (double)count, eps, momentum);
   return fmi_launch_status();
 }

@@ -106,21 +106,30 @@ class DataParallelOptimizer:
             print(f"[fmi.dist r{dist.get_rank()}] bucket #{self.collectives} of {type(self.optimizer).__name__}@{id(self) & 0xffff:x}: "
                   f"{len(params)} tensors, {flat.numel() * 4} bytes", file=sys.stderr, flush=True)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((work, flat, params))
+        self._inflight.append((work, flat, params, [p.grad.numel() for p in params]))
         self.collectives += 1
 
     def _finish(self):
         self.launch()
         world = dist.get_world_size(self.group)
-        for work, flat, params in self._inflight:
+        for work, flat, params, sizes in self._inflight:
             work.wait()
             flat.div_(world)
-            views, off = [], 0
-            for p in params:
-                n = p.grad.numel()
-                views.append(flat[off:off + n].view_as(p.grad))
+            dst, views, off = [], [], 0
+            for p, n in zip(params, sizes):
+                if p.grad is not None and p.grad.numel() == n:  # a gradient cleared (set_to_none) after its bucket left is skipped
+                    dst.append(p.grad)
+                    views.append(flat[off:off + n].view_as(p.grad))
                 off += n
-            torch._foreach_copy_([p.grad for p in params], views)
+            if dst:
+                torch._foreach_copy_(dst, views)
+        self._inflight = []
+
+    def _drop_inflight(self):
+        """a backward fired the hooks but no step() followed (skipped step, exception, validation backward): the collectives
+        must still complete on every rank, their results are discarded"""
+        for work, _flat, _params, _sizes in self._inflight:
+            work.wait()
         self._inflight = []
 
     @property
@@ -129,6 +138,7 @@ class DataParallelOptimizer:
 
     def zero_grad(self, *a, **k):
         self._open, self._open_bytes = [], 0
+        self._drop_inflight()
         return self.optimizer.zero_grad(*a, **k)
 
     def state_dict(self):

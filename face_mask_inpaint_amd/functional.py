@@ -1445,7 +1445,7 @@ def subsample(x, stride):
 
 class _BatchNormTrain(torch.autograd.Function):
     """BatchNorm2d (training statistics) on NHWC: statistics over (N, H, W) per channel = the instance-norm kernels with the
-    batch folded into the pixel axis.  Returns (y, stats[C][2] = (mean, rstd))."""
+    batch folded into the pixel axis.  Returns (y, stats[1][C][2] = (mean, rstd), sums[1][C][2] = fp64 (sum, sum of squares))."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -1459,12 +1459,12 @@ class _BatchNormTrain(torch.autograd.Function):
         y = torch.empty_like(x)
         lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), 1, rows, c, 1.0, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
-        ctx.mark_non_differentiable(stats)
+        ctx.mark_non_differentiable(stats, sums)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output (one fill launch per BatchNorm and step)
-        return y, stats
+        return y, stats, sums
 
     @staticmethod
-    def backward(ctx, g, _gstats):
+    def backward(ctx, g, _gstats, _gsums):
         lib = _L()
         x, stats, gamma, beta = ctx.saved_tensors
         c = x.shape[-1]
@@ -1479,14 +1479,16 @@ class _BatchNormTrain(torch.autograd.Function):
         return gx, dg, db, None
 
 
-def batch_norm_running_update(stats, running_mean, running_var, num_batches_tracked, count, eps, momentum):
-    """in-place momentum update of the BatchNorm2d buffers from stats [1, C, 2] = (mean, rstd) of the batch (one launch)"""
+def batch_norm_running_update(stats, running_mean, running_var, num_batches_tracked, count, eps, momentum, sums=None):
+    """in-place momentum update of the BatchNorm2d buffers from stats [1, C, 2] = (mean, rstd) of the batch (one launch); sums = the
+    fp64 (sum, sum of squares) of the same pass, from which the variance is taken when given"""
     _chk(stats, running_mean, running_var)
+    _chk(sums, dtype=torch.float64)
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise FmiError("num_batches_tracked must be an int64 device tensor")
     nbt = C.c_void_p(num_batches_tracked.data_ptr()) if num_batches_tracked is not None else None
-    _L().batchnorm_running_update_f32(_p(stats), _p(running_mean), _p(running_var), nbt, running_mean.numel(), int(count), float(eps),
-                                      float(momentum), _st())
+    _L().batchnorm_running_update_f32(_p(stats), C.c_void_p(sums.data_ptr()) if sums is not None else None, _p(running_mean),
+                                      _p(running_var), nbt, running_mean.numel(), int(count), float(eps), float(momentum), _st())
 
 
 def batch_norm_train(x, gamma, beta, eps=1e-5):
@@ -1494,7 +1496,7 @@ def batch_norm_train(x, gamma, beta, eps=1e-5):
 
 
 def channel_affine(x, scale, shift):
-    """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); scale/shift are plain (no-grad) tensors"""
+    """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); gradients reach scale / shift when they require them"""
     n = x.shape[0]
     c = x.shape[-1]
     y = scale_channels(x.reshape(1, -1, c), scale.view(1, c).contiguous())
@@ -1511,7 +1513,13 @@ class _BiasAdd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        gb = None
+        if ctx.needs_input_grad[1]:
+            g = g.contiguous()
+            c = g.shape[-1]
+            gb = _zeros(c, g.device, torch.float32)
+            _L().bias_grad_f32(_p(g), g.numel() // c, c, c, _p(gb), _st())
+        return g, gb
 
 
 # ---------------------------------------------------------------------------------------------------

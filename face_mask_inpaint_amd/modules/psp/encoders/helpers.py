@@ -38,22 +38,26 @@ def get_blocks(num_layers):
 def batch_norm(bn: BatchNorm2d, x):
     """nn.BatchNorm2d forward on NHWC with torch's training / eval semantics"""
     if bn.training or not bn.track_running_stats:
-        y, stats = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps)
+        y, stats, sums = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps)
         if bn.training and bn.track_running_stats:
             cnt = x.numel() // x.shape[-1]
             if bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
                 with torch.no_grad():  # one launch: momentum update of both buffers and the batch counter
-                    FF.batch_norm_running_update(stats, bn.running_mean, bn.running_var, bn.num_batches_tracked, cnt, bn.eps, bn.momentum)
+                    FF.batch_norm_running_update(stats, bn.running_mean, bn.running_var, bn.num_batches_tracked, cnt, bn.eps, bn.momentum, sums)
                 return y
             with torch.no_grad():  # cumulative moving average (momentum=None): [C]-sized torch bookkeeping
                 mean = stats[0, :, 0]
-                var = (1.0 / stats[0, :, 1] ** 2 - bn.eps) * (cnt / max(cnt - 1, 1))
+                m64 = sums[0, :, 0] / cnt
+                var = ((sums[0, :, 1] / cnt - m64 * m64).clamp_min(0) * (cnt / max(cnt - 1, 1))).float()
                 m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
                 bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
                 bn.running_var.mul_(1 - m).add_(var, alpha=m)
                 bn.num_batches_tracked += 1
         return y
-    with torch.no_grad():
+    # eval mode: frozen statistics, but the affine parameters still receive gradients like torch.nn.BatchNorm2d's do
+    # ([C]-sized torch bookkeeping; the per-pixel work and its reductions are the library's)
+    want = torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)
+    with torch.enable_grad() if want else torch.no_grad():
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
     return FF.channel_affine(x, scale, shift)

@@ -39,7 +39,11 @@ class FusedLeakyReLUFunctionBackward(Function):
         n, c = grad_input.shape[0], grad_input.shape[1]
         hw = grad_input.numel() // (n * c)
         grad_bias = torch.zeros(c, device=grad_input.device, dtype=torch.float32)
-        _lib.lib().bias_grad_nchw_f32(_p(grad_input), n, c, hw, _p(grad_bias), _st())
+        # the sum reads the cotangent in ITS dtype (a bf16 buffer handed to the fp32 entry would be read out of bounds)
+        fn = _lib.lib().bias_grad_nchw_bf16 if grad_input.dtype == torch.bfloat16 else _lib.lib().bias_grad_nchw_f32
+        _chk(grad_input, dtype=grad_input.dtype if grad_input.dtype == torch.bfloat16 else torch.float32)
+        if grad_input.numel():
+            fn(_p(grad_input), n, c, hw, _p(grad_bias), _st())
         return grad_input, grad_bias
 
     @staticmethod

@@ -299,9 +299,11 @@ int fmi_instnorm_stats_f32(const float* x, double* sums /*[N][C][2]*/, float* st
 int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
                            int N, int HW, int C, float slope, void* stream);
 /* nn.BatchNorm2d running statistics (helpers.py:83-113 run BatchNorm2d in training mode) from stats[C][2] = (mean, rstd) of the batch:
- * running = (1 - momentum) * running + momentum * (mean | unbiased variance), num_batches_tracked[0] += 1 (may be NULL) */
-int fmi_batchnorm_running_update_f32(const float* stats, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
-                                     int64_t count, float eps, float momentum, void* stream);
+ * running = (1 - momentum) * running + momentum * (mean | unbiased variance), num_batches_tracked[0] += 1 (may be NULL).
+ * sums[C][2] (may be NULL) = the fp64 (sum, sum of squares) fmi_instnorm_stats_f32 wrote: the variance is then taken from them
+ * instead of being reconstructed as 1 / rstd^2 - eps */
+int fmi_batchnorm_running_update_f32(const float* stats, const double* sums, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, int C, int64_t count, float eps, float momentum, void* stream);
 /* backward of y = lrelu(IN(x)): red[n][c] = {sum g', sum g'*xhat} (ws as above), then gx; dgamma/dbeta += */
 int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
                                 const float* beta, double* red, int N, int HW, int C, float slope, double* ws, int64_t ws_doubles,
@@ -374,6 +376,8 @@ int fmi_fused_bias_act_bf16(const uint16_t* x, const uint16_t* bias, const uint1
                             int size_b, int act, int grad, float alpha, float scale, void* stream);
 /* dbias[c] += sum_{n,hw} g[n][c][hw] for NCHW g (grad_bias of FusedLeakyReLU, op/fused_act.py:29-36); caller zeroes dbias */
 int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream);
+/* the same sum for a bf16 cotangent (fused_leaky_relu on a bf16 tensor); dbias stays fp32 */
+int fmi_bias_grad_nchw_bf16(const void* g, int N, int C, int64_t HW, float* dbias, void* stream);
 /* NHWC variant used by the product's StyledConv: y = lrelu(x + bias[c] + nw[0]*noise[p]) * scale */
 int fmi_noise_bias_act_f32(const float* x, const float* bias, const float* noise, const float* nw, float* y,
                            int64_t pixels, int C, float alpha, float scale, void* stream);

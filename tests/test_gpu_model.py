@@ -118,7 +118,7 @@ def test_two_training_steps_against_reference_golden(dev, golden):
             # relative to sum|terms|, not to the result, hence the wider absolute floor for 1-D tensors.
             # End-to-end gradients of this tiny random-init network are ill-conditioned with respect to forward rounding: a
             # 1e-7 relative perturbation of ONE early convolution output moves the generator's parameter gradients by up to
-            # 1.2e-3 of their largest entry (scripts/exp/perturb.py, measured with one and the same library build), i.e. an
+            # 1.2e-3 of their largest entry (tools/bench_tools/perturb.py, measured with one and the same library build), i.e. an
             # amplification of ~1e4; every GEMM-family kernel rounds differently from the CPU reference at the 1e-7 level, so
             # ~30 such contributions bound the generator's gradients at 4e-2.  Kernel- and block-level tests hold 1e-5..2e-4.
             err = (got[n] - g).abs().max()
@@ -304,7 +304,7 @@ def test_generator_gradients_without_contextual_term(dev, golden):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         # per tensor: largest deviation within 4e-2 of the largest entry and relative L2 error within 2e-2 -- the conditioning
-        # bound explained in test_two_training_steps_against_reference_golden (measured: scripts/exp/perturb.py)
+        # bound explained in test_two_training_steps_against_reference_golden (measured: tools/bench_tools/perturb.py)
         err = float((p.grad.cpu() - want).abs().max())
         lim = 4e-2 * float(want.abs().max()) + (1e-6 if want.ndim == 1 else 1e-7)
         assert err <= lim, f"{n}: {err:.3e} > {lim:.3e}"

@@ -53,7 +53,6 @@ def test_upfirdn2d_autograd(dev):
         gy = torch.randn(y.shape, generator=g)
         (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
         ggx = torch.randn(gx.shape, generator=g)
-        (ggy,) = torch.autograd.grad(gx, gy if gy.requires_grad else x, ggx, allow_unused=True) if False else (None,)
         xd = x.detach().to(dev).requires_grad_(True)
         gyd = gy.to(dev).requires_grad_(True)
         yd = upfirdn2d(xd, k.to(dev), up=up, down=down, pad=pad)
@@ -235,6 +234,20 @@ def test_native_ops_bf16(dev, golden):
     got = fused_bias_act(x.to(dev), x.new_empty(0).to(dev), ref.to(dev), 3, 1, 0.2, 2 ** 0.5)  # gradient form
     want = (torch.where(ref.float() > 0, x.float(), x.float() * 0.2) * 2 ** 0.5).to(torch.bfloat16)
     close_bf16(got, want)
+    # autograd through fused_leaky_relu on a bf16 tensor: grad_input (bf16) and grad_bias (fp32 sums over the bf16 grad_input, read in
+    # ITS dtype) against an fp32 evaluation with the kernel's sign rule (sign of the saved bf16 output)
+    xb_ = torch.randn(3, 6, 9, 7, generator=g).to(torch.bfloat16)
+    bb_ = torch.randn(6, generator=g)
+    gyb = torch.randn(3, 6, 9, 7, generator=g).to(torch.bfloat16)
+    xd = xb_.to(dev).requires_grad_(True)
+    bd = bb_.to(dev).requires_grad_(True)
+    out = fused_leaky_relu(xd, bd)
+    assert out.dtype == torch.bfloat16
+    out.backward(gyb.to(dev))
+    gin = (torch.where(out.detach().float().cpu() > 0, gyb.float(), gyb.float() * 0.2) * 2 ** 0.5).to(torch.bfloat16)
+    close_bf16(xd.grad, gin)
+    assert bd.grad.dtype == torch.float32
+    torch.testing.assert_close(bd.grad.cpu(), gin.float().sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-5)
     # bandwidth at the 1024^2 decoder's Blur shape: 4 images x 32 channels, 1025^2 -> 1024^2, bf16
     xb = torch.randn(4 * 32, 1025, 1025, device=dev).to(torch.bfloat16)
     from face_mask_inpaint_amd.modules.psp.stylegan2.op.upfirdn2d import _native

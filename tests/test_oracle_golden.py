@@ -29,7 +29,7 @@ def _check_block(fx, fn):
 
 
 def test_resblock_none(golden):
-    _check_block(golden("picnet_ops.pt")["resblock_none"], lambda P, x: O.res_block(P, "", x, "none") if False else O.res_block(_strip(P), "b", x, "none"))
+    _check_block(golden("picnet_ops.pt")["resblock_none"], lambda P, x: O.res_block(_strip(P), "b", x, "none"))
 
 
 def _strip(P):

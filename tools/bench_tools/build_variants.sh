@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds libfmi_hip variants with -DFMI_EXP=<mask> (timing experiments on the GEMM core) into scripts/exp/_build/
+# builds libfmi_hip variants with -DFMI_EXP=<mask> (timing experiments on the GEMM core) into tools/bench_tools/_build/
 set -e
 cd "$(dirname "$0")"
 CS=../../face_mask_inpaint_amd/csrc
