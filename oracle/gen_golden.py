@@ -132,6 +132,8 @@ def picnet_train_fixture():
     tdn._standard_normal = feeder
     try:
         for step in range(2):
+            if step:  # state at the start of step 1 (parameters after one Adam step, SpectralNorm u/v after 1 G / 3 D forwards)
+                fx["G_sd1"], fx["D_sd1"] = sd_clone(G), sd_clone(D)
             src = torch.rand(n, 3, s, s, generator=g)
             ref = torch.rand(n, 3, s, s, generator=g)
             gt = torch.rand(n, 3, s, s, generator=g)
@@ -147,6 +149,50 @@ def picnet_train_fixture():
         fx["G_sd2"], fx["D_sd2"] = sd_clone(G), sd_clone(D)
     finally:
         tdn._standard_normal = old
+
+    # ---- the SAME two steps evaluated by the reference in float64, each restarted from the fp32 run's state at the start of
+    # that step: the adjudicator for the end-to-end gradient bound (how far is the reference's OWN fp32 run from the true
+    # gradient of this ill-conditioned tiny network?).  Stored rounded to fp32 (6e-8 relative, far below either error).
+    class Replay:
+        def __init__(self, draws):
+            self.draws, self.i = draws, 0
+
+        def __call__(self, shape, dtype, device):
+            e = self.draws[self.i].to(dtype)
+            self.i += 1
+            return e
+
+    torch.set_default_dtype(torch.float64)
+    try:
+        for step in range(2):
+            G64 = ref_model.ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(64, 64)).double()
+            D64 = ref_network.define_d(**disc).double()
+            G64.load_state_dict({k: v.double() for k, v in fx[f"G_sd{step}"].items()}, strict=False)
+            D64.load_state_dict({k: v.double() for k, v in fx[f"D_sd{step}"].items()}, strict=False)
+            oG = SpyAdam([(n_, p) for n_, p in G64.named_parameters() if p.requires_grad], lr)
+            oD = SpyAdam([(n_, p) for n_, p in D64.named_parameters() if p.requires_grad], lr)
+            gopt64 = ref_loss.GANOptimizer(oD, oG)
+            gopt64.vgg_loss.double()
+            gopt64.vgg_loss.load_state_dict({k: v.double() for k, v in fx["V_sd"].items()}, strict=False)
+            st = fx[f"step{step}"]
+            tdn._standard_normal = Replay([st["eps_p"], st["eps_q"]])
+            try:
+                tm = (st["mask"] > 0).double()
+                gen = G64(st["src"].double(), st["ref"].double(), src_mask=tm)
+                out = gopt64(D64, st["src"].double(), st["gt"].double(), st["ref"].double(), gen, tm)
+            finally:
+                tdn._standard_normal = old
+            st["gen64"] = gen.detach().float()
+            st["losses64"] = torch.stack([o.detach() for o in out])  # float64: d_loss, g_loss, perc, style, cx
+            st["G_grads64"] = {k: v.float() for k, v in oG.snaps[0].items()}
+            st["D_grads64"] = {k: v.float() for k, v in oD.snaps[0].items()}
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for step in range(2):  # report: how far is the reference's fp32 run from the fp64 truth?
+        st = fx[f"step{step}"]
+        for key in ("G", "D"):
+            worst = max(((float((st[f"{key}_grads"][k] - v).abs().max() / (v.abs().max() + 1e-30)), k) for k, v in st[f"{key}_grads64"].items() if k in st[f"{key}_grads"]))
+            print(f"  step {step} {key}: reference fp32 vs fp64, worst max-error / max|g| = {worst[0]:.2e} ({worst[1]})")
     fx["config"] = dict(enc_layers=5, enc_L=2, enc_z_nc=8, dec_layers=5, dec_L=0, disc_layers=4, out_size=64, lr=lr, vgg_div=VGG_DIV)
     torch.save(fx, os.path.join(OUT, "picnet_train_tiny.pt"))
     print("picnet_train_tiny: gen", tuple(fx["step1"]["gen"].shape), "G_loss", float(fx["step1"]["g_loss"]))
