@@ -543,3 +543,137 @@ def patchdis_fixture():
 
 if __name__ == "__main__":
     patchdis_fixture()
+
+
+def _import_stylegan2():
+    """modules.psp.stylegan2.model with the native ops re-bound to the reference's own upfirdn2d_native / the arithmetic of
+    fused_bias_act_kernel.cu (SURVEY.md section 8c stub 2)"""
+    import torch.utils.cpp_extension as cpp_ext
+    import torch.nn.functional as F
+
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    install_torchvision_stub()
+    cpp_ext.load = lambda *a, **k: None
+    import modules.psp.stylegan2.op  # noqa: F401
+    U = sys.modules["modules.psp.stylegan2.op.upfirdn2d"]
+    U.F = F
+    op = sys.modules["modules.psp.stylegan2.op"]
+
+    def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+        n, c, h, w = input.shape
+        out = U.upfirdn2d_native(input.reshape(-1, h, w, 1), kernel, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+        return out.view(n, c, out.shape[1], out.shape[2])
+
+    def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+        return F.leaky_relu(input + bias.view(1, -1, *([1] * (input.ndim - 2))), negative_slope) * scale
+
+    class FusedLeakyReLU(torch.nn.Module):
+        def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+            super().__init__()
+            self.bias = torch.nn.Parameter(torch.zeros(channel))
+            self.negative_slope, self.scale = negative_slope, scale
+
+        def forward(self, x):
+            return fused_leaky_relu(x, self.bias, self.negative_slope, self.scale)
+
+    op.upfirdn2d, op.fused_leaky_relu, op.FusedLeakyReLU = upfirdn2d, fused_leaky_relu, FusedLeakyReLU
+    from modules.psp.stylegan2 import model as sg
+    return sg
+
+
+def generator_fixture():
+    """the WHOLE StyleGAN2 Generator (stylegan2/model.py:372-550) at Generator(64, 512, 2): parameters are not stored -- both sides
+    fill them from oracle/seeded.py -- only inputs, outputs and gradient digests.  Case "wplus": the call pSp makes (W+ codes,
+    input_is_latent, fixed noise buffers) with backward; case "mix": two z codes through the mapping network, style mixing at a fixed
+    inject_index, truncation, explicit noise list, return_features.  Every gradient digest is stored twice: from the reference's
+    fp32 run and from its float64 run (``*64``, the adjudicator for cancellation-prone reductions such as the noise weights)."""
+    sg = _import_stylegan2()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from seeded import grad_digest, seeded_fill_, seeded_tensor
+
+    SIZE, SEED = 64, 4242
+    fx = {"config": dict(size=SIZE, style_dim=512, n_mlp=2, seed=SEED)}
+    for dt, sfx in ((torch.float32, ""), (torch.float64, "64")):
+        gen = sg.Generator(SIZE, 512, 2)
+        seeded_fill_(gen, SEED)
+        gen = gen.to(dt)
+        lat = seeded_tensor((2, gen.n_latent, 512), 11).to(dt).requires_grad_(True)
+        img, out_lat = gen([lat], input_is_latent=True, randomize_noise=False, return_latents=True)
+        (img * seeded_tensor(img.shape, 12).to(dt)).sum().backward()
+        c = fx.setdefault("wplus", dict(latent_seed=11, cot_seed=12))
+        c["image" + sfx], c["glatent" + sfx] = img.detach().float(), lat.grad.float()
+        c["gparams" + sfx] = {n: grad_digest(p.grad.float(), 1024) for n, p in gen.named_parameters() if p.grad is not None}
+        if not sfx:
+            c["latent_out"] = out_lat.detach().clone()
+            c["no_grad"] = sorted(n for n, p in gen.named_parameters() if p.grad is None)
+        gen.zero_grad()
+        z1 = seeded_tensor((2, 512), 21).to(dt).requires_grad_(True)
+        z2 = seeded_tensor((2, 512), 22).to(dt)
+        tl = seeded_tensor((1, 512), 23, 0.5).to(dt)
+        noise = [seeded_tensor(getattr(gen.noises, f"noise_{i}").shape, 30 + i).to(dt) for i in range(gen.num_layers)]
+        img, feat = gen([z1, z2], return_features=True, inject_index=3, truncation=0.7, truncation_latent=tl, noise=noise)
+        (img * seeded_tensor(img.shape, 24).to(dt)).sum().backward()
+        m = fx.setdefault("mix", dict(z_seeds=(21, 22), trunc_seed=23, noise_seed0=30, cot_seed=24, inject_index=3, truncation=0.7))
+        m["image" + sfx], m["gz1" + sfx] = img.detach().float(), z1.grad.float()
+        m["feature" + sfx] = grad_digest(feat.float(), 4096)
+        m["gparams" + sfx] = {n: grad_digest(p.grad.float(), 256) for n, p in gen.named_parameters() if p.grad is not None and n.startswith("style.")}
+        if not sfx:
+            with torch.no_grad():
+                fx["mean_latent_input"] = dict(seed=25, out=gen.get_latent(seeded_tensor((4, 512), 25)))
+    torch.save(fx, os.path.join(OUT, "stylegan2_generator.pt"))
+    print("stylegan2_generator: image", tuple(img.shape), "%.2f MB" % (os.path.getsize(os.path.join(OUT, "stylegan2_generator.pt")) / 1e6))
+
+
+def psp_whole_fixture():
+    """the WHOLE pSp (psp.py:72-119) at full widths in TRAINING mode: IR-SE50 GradualStyleEncoder with attention on src + ref,
+    latent_avg, the 256^2 StyleGAN2 decoder (BASELINE configs[2] shapes at batch 2), forward + backward.  Parameters from
+    oracle/seeded.py; stored: inputs' seeds, images, latents, gradient digests (fp32 run and float64 run of the reference), a few
+    BatchNorm running statistics."""
+    sg = _import_stylegan2()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from seeded import grad_digest, seeded_fill_, seeded_tensor
+    from modules.psp import psp as P
+
+    P.pSp.load_weights = lambda self: setattr(self, "latent_avg", None)  # SURVEY.md 8c stub 3: the checkpoint files are absent
+    SEED = 777
+    mask = torch.zeros(2, 256, 256)
+    mask[0, 120:230, 60:200] = 1
+    mask[1, 100:240, 40:180] = 1
+    fx = dict(config=dict(seed=SEED, latent_avg_seed=778, output_size=256, x_seed=31, ref_seed=32, cot_seeds=(33, 34), rects=((120, 230, 60, 200), (100, 240, 40, 180))))
+    for dt, sfx in ((torch.float32, ""), (torch.float64, "64")):
+        opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", use_attention=True, train_decoder=True,
+                                     start_from_latent_avg=True, learn_in_w=False, pt_ckpt_path=None, stylegan_weights=None)
+        net = P.pSp(opts)
+        seeded_fill_(net, SEED)
+        net = net.to(dt)
+        net.latent_avg = seeded_tensor((opts.n_styles, 512), 778, 0.5).to(dt)
+        net.train()
+        x = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(31)) * 2 - 1).to(dt).requires_grad_(True)
+        ref = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(32)) * 2 - 1).to(dt).requires_grad_(True)
+        img, lat = net(x, ref=ref, src_mask=mask.to(dt), resize=True, randomize_noise=False, return_latents=True)
+        ((img * seeded_tensor(img.shape, 33).to(dt)).sum() / 256.0 + (lat * seeded_tensor(lat.shape, 34).to(dt)).sum()).backward()
+        fx["image" + sfx] = img.detach().float() if not sfx else grad_digest(img.detach().float(), 16384)
+        fx["latent" + sfx] = lat.detach().float()
+        fx["gx" + sfx], fx["gref" + sfx] = grad_digest(x.grad.float(), 8192), grad_digest(ref.grad.float(), 8192)
+        fx["gparams" + sfx] = {n: grad_digest(p.grad.float(), 256) for n, p in net.named_parameters() if p.grad is not None}
+        if not sfx:
+            sd = net.state_dict()
+            fx["no_grad"] = sorted(n for n, p in net.named_parameters() if p.grad is None)
+            fx["stats_after"] = {k: sd[k].clone() for k in (
+                "encoder.input_layer.1.running_mean", "encoder.input_layer.1.running_var", "encoder.input_layer.1.num_batches_tracked",
+                "encoder.body.0.res_layer.0.running_var", "encoder.body.7.shortcut_layer.1.running_mean",
+                "encoder.body.23.res_layer.4.running_mean", "encoder.body.23.res_layer.4.running_var")}
+            net.eval()
+            with torch.no_grad():
+                img_e = net(x.detach(), ref=ref.detach(), src_mask=mask, resize=True, randomize_noise=False)
+            fx["image_eval"] = grad_digest(img_e, 16384)
+            print("psp_whole: image range", float(img.min()), float(img.max()), "latent std", float(lat.std()))
+        del net
+    torch.save(fx, os.path.join(OUT, "psp_whole.pt"))
+    print("psp_whole: %.2f MB" % (os.path.getsize(os.path.join(OUT, "psp_whole.pt")) / 1e6))
+
+
+if __name__ == "__main__":
+    generator_fixture()
+    psp_whole_fixture()

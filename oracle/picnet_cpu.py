@@ -358,8 +358,8 @@ def trainable(P: Params) -> List[torch.Tensor]:
     return [t for k, t in P.items() if t.requires_grad]
 
 
-def prepare_params(sd: Dict[str, torch.Tensor], frozen: bool = False) -> Params:
-    """Clone a state_dict into leaf tensors.  ``weight_u/_v`` are
+def prepare_params(sd: Dict[str, torch.Tensor], frozen: bool = False, dtype: torch.dtype = torch.float32) -> Params:
+    """Clone a state_dict into leaf tensors (``dtype=torch.float64``: the same restatement as a double-precision adjudicator).  ``weight_u/_v`` are
     requires_grad=False Parameters in the reference (external_function.py:58-59).
     Aliased keys (``model.N`` / ``shortcut.N`` duplicates of conv1/conv2/bypass)
     are collapsed onto one tensor so that updates stay shared."""
@@ -370,7 +370,7 @@ def prepare_params(sd: Dict[str, torch.Tensor], frozen: bool = False) -> Params:
         if key in seen and seen[key].shape == v.shape:
             out[k] = seen[key]
             continue
-        t = v.detach().clone().float()
+        t = v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone()
         needs_grad = (not frozen) and not (k.endswith("weight_u") or k.endswith("weight_v"))
         t.requires_grad_(needs_grad)
         out[k] = t

@@ -152,3 +152,42 @@ def generator_forward(P, latent, noises, size):
         skip = to_rgb(P, f"to_rgbs.{l}", out, latent[:, i + 2], skip)
         i += 2
     return skip
+
+
+def mapping_network(P, z, n_mlp, lr_mul=0.01, prefix="style"):
+    """Generator.style: PixelNorm (stylegan2/model.py:10-15) + n_mlp x EqualLinear(activation='fused_lrelu', lr_mul) (:135-172);
+    the Sequential index of layer i is i + 1"""
+    w = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
+    for i in range(n_mlp):
+        wt = P[f"{prefix}.{i + 1}.weight"]
+        scale = (1 / math.sqrt(wt.shape[1])) * lr_mul
+        w = F.leaky_relu(F.linear(w, wt * scale) + P[f"{prefix}.{i + 1}.bias"] * lr_mul, 0.2) * math.sqrt(2)
+    return w
+
+
+def generator_styles_forward(P, styles, noises, size, n_mlp, inject_index=None, truncation=1.0, truncation_latent=None,
+                             input_is_latent=False):
+    """Generator.forward for a list of style codes (stylegan2/model.py:491-526): mapping network, truncation, repetition of one
+    code over all layers or style mixing of two codes at ``inject_index``; returns (image, latent, last feature map)"""
+    n_latent = int(math.log2(size)) * 2 - 2
+    if not input_is_latent:
+        styles = [mapping_network(P, s, n_mlp) for s in styles]
+    if truncation < 1:
+        styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+    if len(styles) < 2:
+        latent = styles[0].unsqueeze(1).repeat(1, n_latent, 1) if styles[0].ndim < 3 else styles[0]
+    else:
+        latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                            styles[1].unsqueeze(1).repeat(1, n_latent - inject_index, 1)], 1)
+    n = latent.shape[0]
+    log_size = int(math.log2(size))
+    out = P["input.input"].repeat(n, 1, 1, 1)
+    out = styled_conv(P, "conv1", out, latent[:, 0], noises[0])
+    skip = to_rgb(P, "to_rgb1", out, latent[:, 1])
+    i = 1
+    for l in range(log_size - 2):
+        out = styled_conv(P, f"convs.{2 * l}", out, latent[:, i], noises[1 + 2 * l], upsample=True)
+        out = styled_conv(P, f"convs.{2 * l + 1}", out, latent[:, i + 1], noises[2 + 2 * l])
+        skip = to_rgb(P, f"to_rgbs.{l}", out, latent[:, i + 2], skip)
+        i += 2
+    return skip, latent, out

@@ -80,114 +80,137 @@ def _tiny_models(fx, dev):
     return G, D, gopt.to(dev), optG, optD
 
 
+def _spy(opt, names_params, sink):
+    orig = opt.step
+
+    def step(closure=None):
+        sink.append({n: p.grad.detach().cpu().clone() for n, p in names_params if p.grad is not None})
+        return orig(closure)
+
+    opt.step = step
+
+
+def _reference_fp32_error(fx, key):
+    """worst error of the REFERENCE's own fp32 gradients against its float64 evaluation, relative to each tensor's largest entry,
+    over both golden steps (tensors that are analytically zero -- a conv bias in front of InstanceNorm -- excluded)"""
+    worst = 0.0
+    for step in (0, 1):
+        st = fx[f"step{step}"]
+        for n, g64 in st[f"{key}_grads64"].items():
+            mx = float(g64.abs().max())
+            if mx > 1e-12:
+                worst = max(worst, float((st[f"{key}_grads"][n] - g64).abs().max()) / mx)
+    return worst
+
+
+def _check_grads_fp64(got, st, key, step, net_bound):
+    """HIP gradients against the reference evaluated in float64 (the adjudicator, oracle/gen_golden.py).
+
+    End-to-end gradients of this tiny random-init network differ between ANY two fp32 evaluations by LeakyReLU / ReLU kink flips:
+    a pre-activation whose float64 value is below the forward rounding error (|x| ~ 1e-7, one or two among the millions of a step)
+    lands on the other side of zero and changes one derivative from 1 to 0.1 (tools/bench_tools/kinks.py counts them: step 0 -- HIP
+    flips two inputs of the Output block's LeakyReLU with |x64| = 1.2e-7 / 6.2e-8, the reference's fp32 run flips one of decoder4's;
+    step 1 -- both flip the same element).  Which evaluation flips which element is chance, so the reference's fp32 run is 1e-5 from
+    float64 at step 0 and 1.5e-3 at step 1, the HIP path 1.1e-3 and 1.5e-3.  Hence two bounds:
+      * every tensor: error / max|g64| <= 2 x the WORST such ratio the reference's own fp32 run shows on this fixture (any tensor,
+        either step) -- ~3e-3 for G; the round-1 bound was 4e-2;
+      * per tensor against the reference's error on that same tensor (2 x + a 4e-6 floor): asserted for D (no VGG / decoder kinks
+        in its short backward), reported for G."""
+    worse, n_t = 0, 0
+    for n, g64 in st[f"{key}_grads64"].items():
+        assert n in got, f"missing grad {key}.{n}"
+        mx = float(g64.abs().max())
+        if mx <= 1e-12:  # analytically zero: rounding noise on both sides
+            assert float(got[n].abs().max()) <= 1e-6, f"{key} grad {n} step {step} should vanish"
+            continue
+        err = float((got[n] - g64).abs().max()) / mx
+        ref = float((st[f"{key}_grads"][n] - g64).abs().max()) / mx
+        assert err <= net_bound, f"{key} grad {n} step {step}: {err:.3e} of max|g| > {net_bound:.3e} (reference fp32: {ref:.3e})"
+        n_t += 1
+        if err > 2 * ref + 4e-6:
+            worse += 1
+            assert key != "D", f"D grad {n} step {step}: {err:.3e} > 2 x reference's own {ref:.3e}"
+    print(f"step {step} {key}: {worse} of {n_t} tensors further than 2 x the reference's own fp32 error from float64")
+
+
 def test_two_training_steps_against_reference_golden(dev, golden):
     """ReferenceFill.forward + GANOptimizer.__call__ for two consecutive steps.
 
-    Step 0 is checked against the golden vectors of the imported reference: generated image, all five losses and
-    every parameter gradient (captured just before each optimiser step).
-    Adam's first updates are lr * g / (|g| + 1e-8): for parameters whose gradient is at the 1e-8 level (tiny
-    fixture, lr = 1e-3) rounding noise in g is amplified into the 1e-5..1e-4 range of the parameters, so step 1 is
-    checked two ways: (a) strictly against the CPU oracle re-started from THIS run's post-step-0 state (isolates the
-    second forward/backward incl. the evolved SpectralNorm u/v), (b) loosely against the golden end state."""
+    Step 0 from the golden initial state: generated image and all five losses against the imported reference (1e-3), every
+    parameter gradient (captured just before each optimiser step) against the reference's FLOAT64 evaluation with bounds derived
+    from the reference's own fp32-vs-float64 error (see _check_grads_fp64).
+    Step 1 two ways: (a) continued on this run's own post-step-0 state: image and losses against the golden (Adam's first update
+    is lr * g / (|g| + 1e-8), so rounding noise in ~1e-8 gradients moves parameters by up to lr -- hence loose end-state bounds);
+    (b) restarted from the REFERENCE's state at the start of step 1 (G_sd1 / D_sd1 incl. SpectralNorm u/v): gradients against
+    float64 as in step 0."""
     from face_mask_inpaint_amd import functional as FF
-    from oracle import picnet_cpu as O  # checker
 
     fx = golden("picnet_train_tiny.pt")
     cfg = fx["config"]
-    G, D, gopt, optG, optD = _tiny_models(fx, dev)
-    grads = {"G": [], "D": []}
+    bound_g = 2 * _reference_fp32_error(fx, "G")
+    bound_d = max(2 * _reference_fp32_error(fx, "D"), 1e-5)
+    assert bound_g < 5e-3 and bound_d < 1e-4, (bound_g, bound_d)
 
-    def spy(opt, names_params, key):
-        orig = opt.step
-
-        def step(closure=None):
-            grads[key].append({n: p.grad.detach().cpu().clone() for n, p in names_params if p.grad is not None})
-            return orig(closure)
-
-        opt.step = step
-
-    spy(optG, list(G.named_parameters()), "G")
-    spy(optD, list(D.named_parameters()), "D")
-
-    def check_grads(got, ref, key, step):
-        for n, g in ref.items():
-            assert n in got, f"missing grad {key}.{n}"
-            # relative to the tensor's largest entry; the 1e-7 floor covers gradients that are analytically zero
-            # (a conv bias in front of InstanceNorm) and hold only rounding noise on both sides
-            # Bias gradients are sums over all pixels of signed terms (cancellation): their error is bounded
-            # relative to sum|terms|, not to the result, hence the wider absolute floor for 1-D tensors.
-            # End-to-end gradients of this tiny random-init network are ill-conditioned with respect to forward rounding: a
-            # 1e-7 relative perturbation of ONE early convolution output moves the generator's parameter gradients by up to
-            # 1.2e-3 of their largest entry (tools/bench_tools/perturb.py, measured with one and the same library build), i.e. an
-            # amplification of ~1e4; every GEMM-family kernel rounds differently from the CPU reference at the 1e-7 level, so
-            # ~30 such contributions bound the generator's gradients at 4e-2.  Kernel- and block-level tests hold 1e-5..2e-4.
-            err = (got[n] - g).abs().max()
-            rel = 4e-2 if key == "G" else 5e-3
-            lim = (max(rel, 1e-2) * g.abs().max() + 1e-6) if g.ndim == 1 else (rel * g.abs().max() + 1e-7)
-            assert err <= lim, f"{key} grad {n} step {step}: max error {err:.3e} > {lim:.3e}"
-
-    def run_step(s):
+    def run_step(G, D, gopt, s):
         m = FF.binarise_mask(s["mask"].to(dev))
         assert torch.equal(m.cpu(), (s["mask"] > 0).float())
         gen = G(s["src"].to(dev), s["ref"].to(dev), src_mask=m, eps=(s["eps_p"].to(dev), s["eps_q"].to(dev)))
         return gen, gopt(D, s["src"].to(dev), s["gt"].to(dev), s["ref"].to(dev), gen, m)
 
-    # ---- step 0 against the reference's golden vectors
-    s = fx["step0"]
-    gen, (d_loss, g_loss, perc, sty, cx) = run_step(s)
-    torch.testing.assert_close(gen.detach().cpu(), s["gen"], rtol=1e-3, atol=1e-5)
-    for got, key in ((g_loss, "g_loss"), (d_loss, "d_loss"), (perc, "perc"), (sty, "style"), (cx, "cx")):
-        torch.testing.assert_close(got.detach().cpu(), s[key], rtol=1e-3, atol=1e-9, msg=lambda mm, key=key: f"{key} step 0: {mm}")
-    check_grads(grads["G"][0], s["G_grads"], "G", 0)
-    check_grads(grads["D"][0], s["D_grads"], "D", 0)
+    def check_outputs(gen, losses, s, step):
+        torch.testing.assert_close(gen.detach().cpu(), s["gen"], rtol=1e-3, atol=1e-5)
+        d_loss, g_loss, perc, sty, cx = losses
+        for got, key in ((g_loss, "g_loss"), (d_loss, "d_loss"), (perc, "perc"), (sty, "style"), (cx, "cx")):
+            torch.testing.assert_close(got.detach().cpu(), s[key], rtol=1e-3, atol=1e-9, msg=lambda mm, key=key: f"{key} step {step}: {mm}")
+        for got, want in zip(losses, s["losses64"]):  # and the float64 values
+            assert abs(float(got) / float(want) - 1) <= 1e-3
 
-    # ---- step 1 against the oracle restarted from this run's state
-    PG = O.prepare_params({k: v.cpu() for k, v in G.state_dict().items()})
-    PD = O.prepare_params({k: v.cpu() for k, v in D.state_dict().items()})
-    PV = O.prepare_params(fx["V_sd"], frozen=True)
+    # ---- step 0, then step 1 on this run's own state
+    G, D, gopt, optG, optD = _tiny_models(fx, dev)
+    grads = {"G": [], "D": []}
+    _spy(optG, list(G.named_parameters()), grads["G"])
+    _spy(optD, list(D.named_parameters()), grads["D"])
+    gen, losses = run_step(G, D, gopt, fx["step0"])
+    check_outputs(gen, losses, fx["step0"], 0)
+    _check_grads_fp64(grads["G"][0], fx["step0"], "G", 0, bound_g)
+    _check_grads_fp64(grads["D"][0], fx["step0"], "D", 0, bound_d)
+    # state after step 0 against the reference's (parameters: +-lr per element whose gradient is rounding noise; u/v: tight)
+    for mod, key in ((G, "G_sd1"), (D, "D_sd1")):
+        sd = mod.state_dict()
+        for k, v in fx[key].items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-4, atol=1e-6, msg=lambda mm, k=k: f"{k}: {mm}")
+            else:
+                assert float((sd[k].cpu() - v).abs().max()) <= 2.2 * cfg["lr"], k
     s = fx["step1"]
-    mask = O.binarise_mask(s["mask"])
-    kw = dict(enc_layers=cfg["enc_layers"], enc_L=cfg["enc_L"], enc_z_nc=cfg["enc_z_nc"], dec_layers=cfg["dec_layers"],
-              dec_L=cfg["dec_L"], out_size=(cfg["out_size"],) * 2)
-    ogen = O.reference_fill_forward(PG, s["src"], s["ref"], mask, s["eps_p"], s["eps_q"], **kw)
-    import torch.nn.functional as F
-
-    og = O.lsgan(O.res_discriminator(PD, "", ogen, cfg["disc_layers"]), True) * O.LAMBDA_G + F.l1_loss(ogen, s["gt"])
-    operc = O.vgg_loss(PV, "", ogen, s["gt"], "perceptual") * O.LAMBDA_PERC
-    osty = O.vgg_loss(PV, "", ogen * (1 - mask).unsqueeze(1), s["src"], "style") * O.LAMBDA_STYLE
-    ocx = O.vgg_loss(PV, "", ogen * mask.unsqueeze(1), s["ref"] * mask.unsqueeze(1), "contextual") * O.LAMBDA_CX
-    og_total = og + operc + osty + ocx
-    og_total.backward()
-    ograds_g = {n: PG[n].grad.clone() for n, _ in G.named_parameters() if PG[n].grad is not None}
-    od = (O.lsgan(O.res_discriminator(PD, "", s["gt"], cfg["disc_layers"]), True)
-          + O.lsgan(O.res_discriminator(PD, "", ogen.detach(), cfg["disc_layers"]), False)) * 0.5
-    for t in PD.values():
-        t.grad = None
-    od.backward()
-    ograds_d = {n: PD[n].grad.clone() for n, _ in D.named_parameters() if PD[n].grad is not None}
-
-    gen, (d_loss, g_loss, perc, sty, cx) = run_step(s)
-    torch.testing.assert_close(gen.detach().cpu(), ogen.detach(), rtol=1e-3, atol=1e-5)
-    for got, want, key in ((g_loss, og_total, "g_loss"), (d_loss, od, "d_loss"), (perc, operc, "perc"), (sty, osty, "style"), (cx, ocx, "cx")):
-        torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-3, atol=1e-9, msg=lambda mm, key=key: f"{key} step 1: {mm}")
-    check_grads(grads["G"][1], ograds_g, "G", 1)
-    check_grads(grads["D"][1], ograds_d, "D", 1)
-    # SpectralNorm state after 2 G forwards / 6 D forwards agrees with the oracle's (which started from ours after step 0)
-    for mod, P in ((G, PG), (D, PD)):
-        for k, v in mod.state_dict().items():
-            alias = ".shortcut." in "." + k or re.search(r"(^|\.)model\.\d+\.module\.", k)
-            if (k.endswith("weight_u") or k.endswith("weight_v")) and not alias and "attn" not in k.split(".model.")[0][-6:]:
-                torch.testing.assert_close(v.cpu(), P[k], rtol=1e-4, atol=1e-6, msg=lambda mm, k=k: f"{k}: {mm}")
-
-    # ---- (b) end state against the golden: the generated image of step 1 and the parameters after two Adam steps
+    gen, losses = run_step(G, D, gopt, s)
     torch.testing.assert_close(gen.detach().cpu(), s["gen"], rtol=0, atol=5e-3)
-    # an element whose gradient is ~0 can move by +-lr per step in either run: hard bound 2 runs x 2 steps x lr (+10 %);
-    # the bulk agrees far better (typically > 98 % of the elements within 2e-4), which is informational only
+    for got, key in zip(losses, ("d_loss", "g_loss", "perc", "style", "cx")):
+        torch.testing.assert_close(got.detach().cpu(), s[key], rtol=2e-2, atol=1e-9, msg=lambda mm, key=key: f"{key} step 1 (own state): {mm}")
+    # an element whose gradient is ~0 can move by +-lr per step in either run: hard bound 2 runs x 2 steps x lr (+10 %)
     for mod, key in ((G, "G_sd2"), (D, "D_sd2")):
         sd = mod.state_dict()
         for k, v in fx[key].items():
             d = (sd[k].cpu() - v).abs()
             assert d.max() <= 4.4 * cfg["lr"], f"{key} {k}: max diff {d.max():.3e}"
+
+    # ---- step 1 restarted from the reference's state at the start of that step
+    f1 = dict(fx)
+    f1["G_sd0"], f1["D_sd0"] = fx["G_sd1"], fx["D_sd1"]
+    G, D, gopt, optG, optD = _tiny_models(f1, dev)
+    grads = {"G": [], "D": []}
+    _spy(optG, list(G.named_parameters()), grads["G"])
+    _spy(optD, list(D.named_parameters()), grads["D"])
+    gen, losses = run_step(G, D, gopt, s)
+    check_outputs(gen, losses, s, 1)
+    _check_grads_fp64(grads["G"][0], s, "G", 1, bound_g)
+    _check_grads_fp64(grads["D"][0], s, "D", 1, bound_d)
+    # SpectralNorm state after this step (2 G forwards / 6 D forwards in total) against the reference's end state
+    for mod, key in ((G, "G_sd2"), (D, "D_sd2")):
+        sd = mod.state_dict()
+        for k, v in fx[key].items():
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-4, atol=1e-6, msg=lambda mm, k=k: f"{k}: {mm}")
 
 
 def test_forward_matches_oracle_at_moderate_size(dev):
@@ -263,9 +286,11 @@ def test_early_discriminator_schedule_equals_reference_order(dev, golden):
 
 
 def test_generator_gradients_without_contextual_term(dev, golden):
-    """G_loss minus the (ill-conditioned) contextual term: GAN + L1 + perceptual + style, backward through the whole
-    generator, against the CPU oracle on the same parameters (bounds: see the conditioning note in the test above).
-    The contextual term alone is compared on d cx / d gen with the bound its conditioning allows."""
+    """G_loss minus the contextual term: GAN + L1 + perceptual + style, backward through the whole generator; and the contextual
+    term alone on d cx / d gen.  Adjudicated by the CPU oracle evaluated in FLOAT64 (the same restatement the golden vectors pin in
+    fp32; its float64 form is pinned to the reference's float64 gradients in tests/test_oracle_golden.py): the HIP error against
+    float64 may not exceed twice the error of the oracle's own fp32 evaluation, per tensor where the loss is smooth (d cx / d gen)
+    and network-wide where LeakyReLU / ReLU kink flips decide (see _check_grads_fp64)."""
     import torch.nn.functional as F
 
     from face_mask_inpaint_amd import functional as FF
@@ -274,19 +299,26 @@ def test_generator_gradients_without_contextual_term(dev, golden):
     fx = golden("picnet_train_tiny.pt")
     cfg, s = fx["config"], fx["step0"]
     G, D, gopt, optG, optD = _tiny_models(fx, dev)
-    PG = O.prepare_params({k: v.cpu() for k, v in G.state_dict().items()})
-    PD = O.prepare_params({k: v.cpu() for k, v in D.state_dict().items()}, frozen=True)
-    PV = O.prepare_params(fx["V_sd"], frozen=True)
-    mask = O.binarise_mask(s["mask"])
     kw = dict(enc_layers=cfg["enc_layers"], enc_L=cfg["enc_L"], enc_z_nc=cfg["enc_z_nc"], dec_layers=cfg["dec_layers"],
               dec_L=cfg["dec_L"], out_size=(cfg["out_size"],) * 2)
-    ogen = O.reference_fill_forward(PG, s["src"], s["ref"], mask, s["eps_p"], s["eps_q"], **kw)
-    ototal = (O.lsgan(O.res_discriminator(PD, "", ogen, cfg["disc_layers"]), True) * O.LAMBDA_G + F.l1_loss(ogen, s["gt"])
-              + O.vgg_loss(PV, "", ogen, s["gt"], "perceptual") * O.LAMBDA_PERC
-              + O.vgg_loss(PV, "", ogen * (1 - mask).unsqueeze(1), s["src"], "style") * O.LAMBDA_STYLE)
-    ototal.backward()
-    og = ogen.detach().clone().requires_grad_(True)
-    (ocx_g,) = torch.autograd.grad(O.vgg_loss(PV, "", og * mask.unsqueeze(1), s["ref"] * mask.unsqueeze(1), "contextual"), og)
+    sd_g = {k: v.cpu() for k, v in G.state_dict().items()}
+    sd_d = {k: v.cpu() for k, v in D.state_dict().items()}
+    names = [n for n, _ in G.named_parameters()]
+    ora = {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        PG = O.prepare_params(sd_g, dtype=dt)
+        PD = O.prepare_params(sd_d, frozen=True, dtype=dt)
+        PV = O.prepare_params(fx["V_sd"], frozen=True, dtype=dt)
+        mask = O.binarise_mask(s["mask"]).to(dt)
+        src, gt, ref = s["src"].to(dt), s["gt"].to(dt), s["ref"].to(dt)
+        ogen = O.reference_fill_forward(PG, src, ref, mask, s["eps_p"].to(dt), s["eps_q"].to(dt), **kw)
+        ototal = (O.lsgan(O.res_discriminator(PD, "", ogen, cfg["disc_layers"]), True) * O.LAMBDA_G + F.l1_loss(ogen, gt)
+                  + O.vgg_loss(PV, "", ogen, gt, "perceptual") * O.LAMBDA_PERC
+                  + O.vgg_loss(PV, "", ogen * (1 - mask).unsqueeze(1), src, "style") * O.LAMBDA_STYLE)
+        ototal.backward()
+        og = s["gen"].to(dt).clone().requires_grad_(True)  # common evaluation point of d cx / d gen: the reference's image
+        (ocx_g,) = torch.autograd.grad(O.vgg_loss(PV, "", og * mask.unsqueeze(1), ref * mask.unsqueeze(1), "contextual"), og)
+        ora[tag] = (float(ototal), {n: PG[n].grad.double() for n in names if PG[n].grad is not None}, ocx_g.double())
 
     m = FF.binarise_mask(s["mask"].to(dev))
     src, gt, ref = s["src"].to(dev), s["gt"].to(dev), s["ref"].to(dev)
@@ -295,30 +327,30 @@ def test_generator_gradients_without_contextual_term(dev, golden):
         p.requires_grad_(False)
     perc, sty = gopt.vgg_loss.forward_multi([(gen, gt, "perceptual"), (gopt._masked(gen, m, True), src, "style")])
     total = gopt.generator_loss(D, gt, gen, freeze=False) + perc * gopt.lambda_perc + sty * gopt.lambda_style
-    torch.testing.assert_close(total.detach().cpu(), ototal.detach(), rtol=1e-4, atol=1e-9)
+    assert abs(float(total) / ora["f64"][0] - 1) <= 1e-5
     total.backward()
+    net_bound = 2 * _reference_fp32_error(fx, "G")
+    g64, g32 = ora["f64"][1], ora["f32"][1]
     worst = []
     for n, p in G.named_parameters():
-        want = PG[n].grad
-        if want is None:
+        if n not in g64:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
-        # per tensor: largest deviation within 4e-2 of the largest entry and relative L2 error within 2e-2 -- the conditioning
-        # bound explained in test_two_training_steps_against_reference_golden (measured: tools/bench_tools/perturb.py)
-        err = float((p.grad.cpu() - want).abs().max())
-        lim = 4e-2 * float(want.abs().max()) + (1e-6 if want.ndim == 1 else 1e-7)
-        assert err <= lim, f"{n}: {err:.3e} > {lim:.3e}"
-        if want.ndim > 1:
-            l2 = float((p.grad.cpu() - want).norm() / (want.norm() + 1e-30))
-            worst.append((l2, n))
+        mx = float(g64[n].abs().max())
+        if mx <= 1e-12:
+            continue
+        err = float((p.grad.cpu().double() - g64[n]).abs().max()) / mx
+        ref_err = float((g32[n] - g64[n]).abs().max()) / mx
+        assert err <= net_bound, f"{n}: {err:.3e} of max|g| > {net_bound:.3e} (oracle fp32: {ref_err:.3e})"
+        worst.append((err, ref_err, n))
     worst.sort(reverse=True)
-    print("worst relative L2 errors:", [("%.2e" % a, b) for a, b in worst[:6]])
-    for l2, n in worst:
-            assert l2 <= 2e-2, f"{n}: relative L2 error {l2:.3e}"
-    g2 = gen.detach().clone().requires_grad_(True)
+    print("worst errors against float64 (HIP, oracle fp32):", [("%.2e" % a, "%.2e" % b, c) for a, b, c in worst[:6]])
+    g2 = s["gen"].to(dev).clone().requires_grad_(True)
     (cx_g,) = torch.autograd.grad(gopt.contextual_loss(g2, ref, m), g2)
-    rel_l2 = float((cx_g.cpu() - ocx_g).norm() / ocx_g.norm())
-    assert rel_l2 <= 5e-2, f"d cx / d gen: relative L2 error {rel_l2:.3e}"
+    c64, c32 = ora["f64"][2], ora["f32"][2]
+    e_hip = float((cx_g.cpu().double() - c64).norm() / c64.norm())
+    e_o32 = float((c32 - c64).norm() / c64.norm())
+    assert e_hip <= 2 * e_o32 + 1e-5, f"d cx / d gen: relative L2 error {e_hip:.3e} against float64 > 2 x the fp32 oracle's {e_o32:.3e}"
 
 
 def test_patch_discriminator_against_reference_golden(dev, golden):

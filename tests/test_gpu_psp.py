@@ -116,6 +116,50 @@ def test_psp_loss_against_reference_golden(dev, golden):
         pSpLoss(types.SimpleNamespace(**{**fx["args"], "lpips_lambda": 0.8}))
 
 
+def test_psp_whole_train_against_reference(dev, golden):
+    """the WHOLE pSp at full widths (IR-SE50 GradualStyleEncoder with attention on src + ref, latent_avg, 256^2 StyleGAN2 decoder:
+    BASELINE configs[2] shapes at batch 2) in TRAINING mode, forward + backward, against the imported reference
+    (tests/golden/psp_whole.pt, oracle/gen_golden.py:psp_whole_fixture; parameters from oracle/seeded.py on both sides): image and
+    W+ codes at 1e-3, the input gradients and EVERY parameter gradient adjudicated by the reference's float64 run, BatchNorm
+    running statistics after the step, then the eval-mode image"""
+    from face_mask_inpaint_amd.modules.psp.psp import pSp
+    from oracle.seeded import check_adjudicated, check_digest, seeded_fill_, seeded_tensor  # checker
+
+    fx = golden("psp_whole.pt")
+    cfg = fx["config"]
+    opts = types.SimpleNamespace(output_size=cfg["output_size"], encoder_type="GradualStyleEncoder", use_attention=True, train_decoder=True,
+                                 start_from_latent_avg=True, learn_in_w=False, pt_ckpt_path=None, stylegan_weights=None)
+    net = pSp(opts)
+    seeded_fill_(net, cfg["seed"])
+    net.latent_avg = seeded_tensor((opts.n_styles, 512), cfg["latent_avg_seed"], 0.5)
+    net.to(dev).train()
+    x = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(cfg["x_seed"])) * 2 - 1).to(dev).requires_grad_(True)
+    ref = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(cfg["ref_seed"])) * 2 - 1).to(dev).requires_grad_(True)
+    mask = torch.zeros(2, 256, 256)
+    for i, (a, b, c, d) in enumerate(cfg["rects"]):
+        mask[i, a:b, c:d] = 1
+    mask = mask.to(dev)
+    img, lat = net(x, ref=ref, src_mask=mask, resize=True, randomize_noise=False, return_latents=True)
+    _close(lat, fx["latent"], 1e-3, "W+ codes")
+    _close(img, fx["image"], 1e-3, "image")
+    ((img * seeded_tensor(img.shape, cfg["cot_seeds"][0]).to(dev)).sum() / 256.0 + (lat * seeded_tensor(lat.shape, cfg["cot_seeds"][1]).to(dev)).sum()).backward()
+    check_adjudicated({"gx": x.grad, "gref": ref.grad}, {"gx": fx["gx"], "gref": fx["gref"]}, {"gx": fx["gx64"], "gref": fx["gref64"]},
+                      floor=3e-3, what="pSp input gradients (HIP)")
+    P = dict(net.named_parameters())
+    check_adjudicated({n: P[n].grad for n in fx["gparams64"]}, fx["gparams"], fx["gparams64"], what="pSp parameters (HIP)")
+    assert sorted(n for n, p in P.items() if p.grad is None) == fx["no_grad"]
+    sd = net.state_dict()
+    for k, v in fx["stats_after"].items():
+        if v.is_floating_point():
+            _close(sd[k], v, 1e-4, k)
+        else:
+            assert int(sd[k]) == int(v), k
+    net.eval()
+    with torch.no_grad():
+        img_e = net(x.detach(), ref=ref.detach(), src_mask=mask, resize=True, randomize_noise=False)
+    check_digest(img_e, fx["image_eval"], 1e-3, "eval image")
+
+
 def test_psp_forward_against_oracle(dev):
     """full-width pSp (IR-SE50 encoder + 256^2 StyleGAN2 decoder), random init, eval-mode BN, explicit noise"""
     from face_mask_inpaint_amd.modules.psp.psp import pSp

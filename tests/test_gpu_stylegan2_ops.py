@@ -147,35 +147,45 @@ def test_modulated_conv_blocks_against_reference_golden(dev, golden):
     _grads_close(m, f["gparams"])
 
 
-def test_generator_against_oracle(dev):
-    """Generator(16, 64, 2): constant input -> conv1/to_rgb1 -> two octaves, fixed noise buffers, W+ latents"""
+def test_generator_whole_against_reference(dev, golden):
+    """the WHOLE Generator(64, 512, 2) against the imported reference (tests/golden/stylegan2_generator.pt; parameters from
+    oracle/seeded.py on both sides): the pSp call form (W+ codes, input_is_latent, noise buffers) with backward -- image, latent
+    gradient and EVERY parameter gradient, adjudicated by the reference's float64 run --, and the sampling form (two z codes through
+    the mapping network, style mixing at a fixed inject_index, truncation, explicit noise list, return_features)"""
     from face_mask_inpaint_amd.modules.psp.stylegan2 import model as sg
-    from oracle import stylegan2_cpu as S  # checker
+    from oracle.seeded import as_digest, check_adjudicated, check_digest, seeded_fill_, seeded_tensor  # checker
 
-    torch.manual_seed(3)
-    gen = sg.Generator(16, 64, 2)
-    with torch.no_grad():
-        for n_, p in gen.named_parameters():
-            if n_.endswith("noise.weight"):
-                p.fill_(0.1)
-    P = {k: v.clone() for k, v in gen.state_dict().items()}
-    g = torch.Generator().manual_seed(4)
-    lat = torch.randn(2, gen.n_latent, 64, generator=g)
-    noises = [getattr(gen.noises, f"noise_{i}").clone() for i in range(gen.num_layers)]
-    want = S.generator_forward(P, lat, noises, 16)
+    fx = golden("stylegan2_generator.pt")
+    cfg = fx["config"]
+    gen = sg.Generator(cfg["size"], cfg["style_dim"], cfg["n_mlp"])
+    seeded_fill_(gen, cfg["seed"])
     gen = gen.to(dev)
-    latd = lat.to(dev).requires_grad_(True)
-    img, _ = gen([latd], input_is_latent=True, randomize_noise=False)
-    torch.testing.assert_close(img.detach().cpu(), want, rtol=1e-3, atol=1e-4)
-    img.square().mean().backward() if False else img.backward(torch.ones_like(img))
-    assert torch.isfinite(latd.grad).all() and latd.grad.abs().sum() > 0
-    # the mapping network (PixelNorm + EqualLinear(fused_lrelu)) against plain torch
-    z = torch.randn(3, 64, generator=g)
-    w = z * torch.rsqrt(torch.mean(z ** 2, dim=1, keepdim=True) + 1e-8)
-    for i in (1, 2):
-        Wt, b = P[f"style.{i}.weight"], P[f"style.{i}.bias"]
-        w = torch.nn.functional.leaky_relu(torch.nn.functional.linear(w, Wt * (1 / 8.0) * 0.01) + b * 0.01, 0.2) * 2 ** 0.5
-    torch.testing.assert_close(gen.get_latent(z.to(dev)).cpu(), w, rtol=1e-4, atol=1e-5)
+    c = fx["wplus"]
+    lat = seeded_tensor((2, gen.n_latent, 512), c["latent_seed"]).to(dev).requires_grad_(True)
+    img, out_lat = gen([lat], input_is_latent=True, randomize_noise=False, return_latents=True)
+    scale = float(c["image"].abs().max())
+    torch.testing.assert_close(img.detach().cpu(), c["image"], rtol=1e-3, atol=1e-4 * scale)
+    torch.testing.assert_close(out_lat.detach().cpu(), c["latent_out"], rtol=0, atol=0)
+    (img * seeded_tensor(img.shape, c["cot_seed"]).to(dev)).sum().backward()
+    P = dict(gen.named_parameters())
+    g32, g64 = dict(c["gparams"], glatent=as_digest(c["glatent"])), dict(c["gparams64"], glatent=as_digest(c["glatent64"]))
+    check_adjudicated(dict({n: P[n].grad for n in c["gparams64"]}, glatent=lat.grad), g32, g64, what="Generator W+ (HIP)")
+    assert sorted(n for n, p in P.items() if p.grad is None) == c["no_grad"]
+    gen.zero_grad()
+    m = fx["mix"]
+    z1 = seeded_tensor((2, 512), m["z_seeds"][0]).to(dev).requires_grad_(True)
+    z2 = seeded_tensor((2, 512), m["z_seeds"][1]).to(dev)
+    tl = seeded_tensor((1, 512), m["trunc_seed"], 0.5).to(dev)
+    nz = [seeded_tensor(getattr(gen.noises, f"noise_{i}").shape, m["noise_seed0"] + i).to(dev) for i in range(gen.num_layers)]
+    img, feat = gen([z1, z2], return_features=True, inject_index=m["inject_index"], truncation=m["truncation"], truncation_latent=tl, noise=nz)
+    torch.testing.assert_close(img.detach().cpu(), m["image"], rtol=1e-3, atol=1e-4 * float(m["image"].abs().max()))
+    check_digest(feat, m["feature"], 1e-4, "feature")
+    (img * seeded_tensor(img.shape, m["cot_seed"]).to(dev)).sum().backward()
+    g32, g64 = dict(m["gparams"], gz1=as_digest(m["gz1"])), dict(m["gparams64"], gz1=as_digest(m["gz164"]))
+    check_adjudicated(dict({n: P[n].grad for n in m["gparams64"]}, gz1=z1.grad), g32, g64, what="Generator mapping network (HIP)")
+    with torch.no_grad():
+        got = gen.get_latent(seeded_tensor((4, 512), fx["mean_latent_input"]["seed"]).to(dev))
+    torch.testing.assert_close(got.cpu(), fx["mean_latent_input"]["out"], rtol=1e-4, atol=1e-5)
 
 
 def test_upfirdn2d_nhwc_vector_and_generic_paths(dev):

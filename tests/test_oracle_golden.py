@@ -81,9 +81,6 @@ def test_two_training_steps(golden):
     kw = dict(enc_layers=cfg["enc_layers"], enc_L=cfg["enc_L"], enc_z_nc=cfg["enc_z_nc"], dec_layers=cfg["dec_layers"],
               dec_L=cfg["dec_L"], out_size=(cfg["out_size"],) * 2)
 
-    def d_fwd_patch():
-        pass
-
     for step in range(2):
         s = fx[f"step{step}"]
         mask = O.binarise_mask(s["mask"])
@@ -109,6 +106,40 @@ def test_two_training_steps(golden):
         torch.testing.assert_close(PG[k].detach(), v, rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f"G param {k}: {m}")
     for k, v in fx["D_sd2"].items():
         torch.testing.assert_close(PD[k].detach(), v, rtol=1e-4, atol=2e-6, msg=lambda m, k=k: f"D param {k}: {m}")
+
+
+def test_two_training_steps_float64(golden):
+    """the same restatement evaluated in float64, each step restarted from the reference's fp32 state at the start of that step,
+    against the reference's own float64 evaluation (gen_golden.py: G_grads64 / D_grads64, stored rounded to fp32): float64 has no
+    kink flips to speak of, so the two agree to fp32 storage precision -- this pins the adjudicator of the GPU gradient tests"""
+    fx = golden("picnet_train_tiny.pt")
+    cfg = fx["config"]
+    kw = dict(enc_layers=cfg["enc_layers"], enc_L=cfg["enc_L"], enc_z_nc=cfg["enc_z_nc"], dec_layers=cfg["dec_layers"],
+              dec_L=cfg["dec_L"], out_size=(cfg["out_size"],) * 2)
+    dt = torch.float64
+    for step in range(2):
+        s = {k: (v.to(dt) if torch.is_tensor(v) and v.dtype == torch.float32 else v) for k, v in fx[f"step{step}"].items()}
+        PG = O.prepare_params(fx[f"G_sd{step}"], dtype=dt)
+        PD = O.prepare_params(fx[f"D_sd{step}"], dtype=dt)
+        PV = O.prepare_params(fx["V_sd"], frozen=True, dtype=dt)
+        mask = O.binarise_mask(s["mask"]).to(dt)
+        gen = O.reference_fill_forward(PG, s["src"], s["ref"], mask, s["eps_p"], s["eps_q"], **kw)
+        torch.testing.assert_close(gen.float(), fx[f"step{step}"]["gen64"], rtol=1e-6, atol=1e-7)
+        g_loss, perc, sty, cx = _gen_losses(PD, PV, s, gen, mask, cfg)
+        g_loss.backward()
+        for n, g in s["G_grads64"].items():
+            lim = 1e-6 * float(g.abs().max()) + 1e-12
+            assert float((PG[n].grad - g.to(dt)).abs().max()) <= lim, f"G grad {n} step {step}"
+        for t in PD.values():
+            t.grad = None
+        d_loss = (O.lsgan(O.res_discriminator(PD, "", s["gt"], cfg["disc_layers"]), True)
+                  + O.lsgan(O.res_discriminator(PD, "", gen.detach(), cfg["disc_layers"]), False)) * 0.5
+        d_loss.backward()
+        for n, g in s["D_grads64"].items():
+            lim = 1e-6 * float(g.abs().max()) + 1e-12
+            assert float((PD[n].grad - g.to(dt)).abs().max()) <= lim, f"D grad {n} step {step}"
+        got = torch.stack([d_loss, g_loss, perc, sty, cx]).detach()
+        torch.testing.assert_close(got, s["losses64"], rtol=1e-6, atol=1e-15)  # an fp32-rounded constant (1e-5, 0.5) on one side: 3e-8
 
 
 def _gen_losses(PD, PV, s, gen, mask, cfg):
@@ -277,3 +308,105 @@ def test_patch_discriminator_oracle(golden):
     for k, v in fx["sd1"].items():
         if k.endswith("weight_u") or k.endswith("weight_v"):
             torch.testing.assert_close(P[k], v, **TOL)
+
+
+# ---- whole models: parameters come from oracle/seeded.py on both sides, the fixture holds I/O and gradient digests -------------
+def _leaf_params(module, trainable=True):
+    """flat name -> leaf tensor dictionary (the oracle's interface) of a module filled by seeded_fill_"""
+    P = {}
+    for k, v in module.state_dict().items():
+        t = v.detach().clone()
+        if trainable and t.is_floating_point() and not (k.endswith(".kernel") or "running_" in k or k.startswith("noises.") or ".noises." in k):
+            t.requires_grad_(True)
+        P[k] = t
+    return P
+
+
+def test_generator_whole_oracle(golden):
+    """oracle generator_forward / generator_styles_forward against the WHOLE reference Generator(64, 512, 2)
+    (tests/golden/stylegan2_generator.pt, oracle/gen_golden.py:generator_fixture): latent indexing, noise order, skip accumulation,
+    mapping network, style mixing, truncation -- with parameter gradients"""
+    from face_mask_inpaint_amd.modules.psp.stylegan2.model import Generator  # parameter container only (no forward on the CPU)
+    from oracle import stylegan2_cpu as S
+    from oracle.seeded import as_digest, check_adjudicated, check_digest, seeded_fill_, seeded_tensor
+
+    fx = golden("stylegan2_generator.pt")
+    cfg = fx["config"]
+    gen = Generator(cfg["size"], cfg["style_dim"], cfg["n_mlp"])
+    seeded_fill_(gen, cfg["seed"])
+    P = _leaf_params(gen)
+    noises = [P[f"noises.noise_{i}"] for i in range(gen.num_layers)]
+    c = fx["wplus"]
+    lat = seeded_tensor((2, gen.n_latent, 512), c["latent_seed"]).requires_grad_(True)
+    img = S.generator_forward(P, lat, noises, cfg["size"])
+    torch.testing.assert_close(img, c["image"], rtol=1e-4, atol=1e-4)
+    (img * seeded_tensor(img.shape, c["cot_seed"])).sum().backward()
+    g32, g64 = dict(c["gparams"], glatent=as_digest(c["glatent"])), dict(c["gparams64"], glatent=as_digest(c["glatent64"]))
+    check_adjudicated(dict({n: P[n].grad for n in c["gparams64"]}, glatent=lat.grad), g32, g64, what="Generator W+")
+    assert sorted(n for n, _ in gen.named_parameters() if P[n].grad is None) == c["no_grad"]  # the mapping network is unused here
+    for t in P.values():
+        t.grad = None
+    m = fx["mix"]
+    z1 = seeded_tensor((2, 512), m["z_seeds"][0]).requires_grad_(True)
+    z2 = seeded_tensor((2, 512), m["z_seeds"][1])
+    tl = seeded_tensor((1, 512), m["trunc_seed"], 0.5)
+    nz = [seeded_tensor(P[f"noises.noise_{i}"].shape, m["noise_seed0"] + i) for i in range(gen.num_layers)]
+    img, latent, feat = S.generator_styles_forward(P, [z1, z2], nz, cfg["size"], cfg["n_mlp"], inject_index=m["inject_index"],
+                                                   truncation=m["truncation"], truncation_latent=tl)
+    torch.testing.assert_close(img, m["image"], rtol=1e-4, atol=1e-4)
+    check_digest(feat, m["feature"], 1e-5, "feature")
+    (img * seeded_tensor(img.shape, m["cot_seed"])).sum().backward()
+    g32, g64 = dict(m["gparams"], gz1=as_digest(m["gz1"])), dict(m["gparams64"], gz1=as_digest(m["gz164"]))
+    check_adjudicated(dict({n: P[n].grad for n in m["gparams64"]}, gz1=z1.grad), g32, g64, what="Generator mapping network")
+    with torch.no_grad():
+        torch.testing.assert_close(S.mapping_network(P, seeded_tensor((4, 512), fx["mean_latent_input"]["seed"]), cfg["n_mlp"]),
+                                   fx["mean_latent_input"]["out"], rtol=1e-5, atol=1e-5)
+
+
+def _psp_whole(cfg):
+    import types
+
+    from face_mask_inpaint_amd.modules.psp.psp import pSp  # parameter container
+    from oracle.seeded import seeded_fill_, seeded_tensor
+
+    opts = types.SimpleNamespace(output_size=cfg["output_size"], encoder_type="GradualStyleEncoder", use_attention=True, train_decoder=True,
+                                 start_from_latent_avg=True, learn_in_w=False, pt_ckpt_path=None, stylegan_weights=None)
+    net = pSp(opts)
+    seeded_fill_(net, cfg["seed"])
+    net.latent_avg = seeded_tensor((opts.n_styles, 512), cfg["latent_avg_seed"], 0.5)
+    x = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(cfg["x_seed"])) * 2 - 1
+    ref = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(cfg["ref_seed"])) * 2 - 1
+    mask = torch.zeros(2, 256, 256)
+    for i, (a, b, c, d) in enumerate(cfg["rects"]):
+        mask[i, a:b, c:d] = 1
+    return net, x, ref, mask
+
+
+def test_psp_whole_oracle(golden):
+    """oracle psp_forward against the WHOLE reference pSp in training mode at full widths (tests/golden/psp_whole.pt,
+    gen_golden.py:psp_whole_fixture): forward + backward incl. train-mode BatchNorm, latent_avg, noise buffers"""
+    from oracle import psp_cpu as PS
+    from oracle.seeded import check_adjudicated, check_digest, seeded_tensor
+
+    fx = golden("psp_whole.pt")
+    cfg = fx["config"]
+    net, x, ref, mask = _psp_whole(cfg)
+    P = _leaf_params(net)
+    x.requires_grad_(True)
+    ref.requires_grad_(True)
+    nl = int(__import__("math").log2(cfg["output_size"]) - 2) * 2 + 1
+    noises = [P[f"decoder.noises.noise_{i}"] for i in range(nl)]
+    img, lat = PS.psp_forward(P, x, ref, mask, noises, cfg["output_size"], latent_avg=net.latent_avg, training=True)
+    scale = float(fx["image"].abs().max())
+    torch.testing.assert_close(lat, fx["latent"], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(img, fx["image"], rtol=1e-3, atol=1e-4 * scale)
+    ((img * seeded_tensor(img.shape, cfg["cot_seeds"][0])).sum() / 256.0 + (lat * seeded_tensor(lat.shape, cfg["cot_seeds"][1])).sum()).backward()
+    check_adjudicated({"gx": x.grad, "gref": ref.grad}, {"gx": fx["gx"], "gref": fx["gref"]}, {"gx": fx["gx64"], "gref": fx["gref64"]},
+                      floor=3e-3, what="pSp input gradients")
+    check_adjudicated({n: P[n].grad for n in fx["gparams64"]}, fx["gparams"], fx["gparams64"], what="pSp parameters")
+    assert sorted(n for n, _ in net.named_parameters() if P[n].grad is None) == fx["no_grad"]
+    for k, v in fx["stats_after"].items():
+        torch.testing.assert_close(P[k], v, rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        img_e, _ = PS.psp_forward(P, x.detach(), ref.detach(), mask, noises, cfg["output_size"], latent_avg=net.latent_avg, training=False)
+    check_digest(img_e, fx["image_eval"], 1e-4, "eval image")
