@@ -402,7 +402,7 @@ def test_psp_whole_oracle(golden):
     torch.testing.assert_close(img, fx["image"], rtol=1e-3, atol=1e-4 * scale)
     ((img * seeded_tensor(img.shape, cfg["cot_seeds"][0])).sum() / 256.0 + (lat * seeded_tensor(lat.shape, cfg["cot_seeds"][1])).sum()).backward()
     check_adjudicated({"gx": x.grad, "gref": ref.grad}, {"gx": fx["gx"], "gref": fx["gref"]}, {"gx": fx["gx64"], "gref": fx["gref64"]},
-                      floor=3e-3, what="pSp input gradients")
+                      floor=5e-3, what="pSp input gradients")
     check_adjudicated({n: P[n].grad for n in fx["gparams64"]}, fx["gparams"], fx["gparams64"], what="pSp parameters")
     assert sorted(n for n, _ in net.named_parameters() if P[n].grad is None) == fx["no_grad"]
     for k, v in fx["stats_after"].items():
