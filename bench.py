@@ -27,11 +27,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-# HBM-side bytes per launch of the dominant kernel, from the rocprofv3 PMC passes committed under profiles/
-# (round1_pmc_attention.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs; FETCH_SIZE doubled as the guide
-# prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE counts the fp32 atomics of the dQ tiles exactly).
-PMC_TRAFFIC_BYTES = {"attn_fused_bwd|T16384 d64 C256 b8": 2 * 746038.0 * 1024 + 4456448.0 * 1024,   # attn_bwd2_kernel<64,8>
-                     "attn_fused_fwd|T16384 d64 C256 b8": 2 * 671539.1 * 1024 + 134025.2 * 1024}   # attn_fwd_kernel<64,8,8>
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def pmc_traffic(call_site_key):
+    """HBM-side bytes per launch of the kernel behind ``call_site_key`` from the rocprofv3 PMC passes committed under profiles/
+    (pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB per launch; FETCH_SIZE doubled as the guide
+    prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE counts fp32 atomics exactly).  The entry names the kernel
+    it was collected on and the sha256 of the kernel's source file at that time: when the source has changed since, the number is
+    STALE and is not reported (traffic = null plus the reason; tests/test_host_modules.py fails on the same condition)."""
+    import hashlib
+
+    try:
+        tab = json.load(open(PMC_TRAFFIC_FILE))
+    except Exception as e:  # noqa: BLE001
+        return None, {"traffic_error": f"profiles/pmc_traffic.json unreadable: {e}"}
+    ent = tab.get(call_site_key)
+    if ent is None:
+        return None, {"traffic_error": f"no PMC profile for {call_site_key!r} in profiles/pmc_traffic.json"}
+    src = os.path.join(ROOT, ent["source"])
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    if sha != ent["source_sha256"]:
+        print(f"[bench] PMC traffic for {call_site_key!r} is STALE: {ent['source']} changed since {ent['profile']} was collected",
+              file=sys.stderr, flush=True)
+        return None, {"traffic_error": f"stale: {ent['source']} changed since {ent['profile']} was collected on {ent['kernel']}"}
+    return 2.0 * ent["fetch_kb"] * 1024 + ent["write_kb"] * 1024, {
+        "traffic_unit": "bytes per launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, %s)" % ent["profile"], "traffic_kernel": ent["kernel"]}
+
+
 ENC = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
 DEC = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
 DISC = dict(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
@@ -100,8 +123,20 @@ def host_cores() -> int:
     return cores
 
 
-def cpu_baseline(size, seconds_budget=30.0):
-    """the CPU port of the same step on this host's cores: bs = 1 (no batch-coupled op on the path), 1 warm-up + timed steps"""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size, seconds_budget=40.0):
+    """the CPU port of the same step on this host's cores (SURVEY.md 8d protocol): fp32, all cores the cgroup grants, bs = 1 (no
+    batch-coupled op on the path), 2 warm-up + >= 5 timed steps, median; plus ONE single-thread step.  Bounded: the timed loop stops
+    after ``seconds_budget`` seconds once 3 steps are in, the single-thread step is skipped when a step would take > 90 s."""
     from oracle import picnet_cpu as O  # checker / baseline only -- never imported by the product package
     from face_mask_inpaint_amd.modules.loss import VGGLoss
     from face_mask_inpaint_amd.modules.model import ReferenceFill
@@ -135,18 +170,28 @@ def cpu_baseline(size, seconds_budget=30.0):
                       "max_abs_err": float((got - wd).abs().max()), "max_rel_to_range": float((got - wd).abs().max() / wd.abs().max()),
                       "mask_bit_exact": bool(torch.equal(FF.binarise_mask(mask.to(dev)).cpu(), O.binarise_mask(mask)))}
         del Gd
+    WARM = 2
     times = []
     t_all = time.time()
-    for it in range(6):
+    for it in range(WARM + 5):
         t0 = time.time()
         O.train_step(PG, PD, PV, og, od, src, gt, ref, mask, eps_p, eps_q, out_size=(size, size))
         times.append(time.time() - t0)
-        if time.time() - t_all > seconds_budget and it >= 1:
+        if time.time() - t_all > seconds_budget and it >= WARM + 2:
             break
-    timed = times[1:] if len(times) > 1 else times
+    timed = times[WARM:]
     sec = sorted(timed)[len(timed) // 2]
-    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port", "parity": parity,
-            "sample": "oracle/picnet_cpu.py train_step at %dx%d, bs=1 (path has no batch-coupled op), 1 warm-up + %d timed steps, median" % (size, size, len(timed))}
+    one = None
+    if sec * cores * 0.7 < 90.0:  # a single-thread step is at most ~cores x slower
+        torch.set_num_threads(1)
+        t0 = time.time()
+        O.train_step(PG, PD, PV, og, od, src, gt, ref, mask, eps_p, eps_q, out_size=(size, size))
+        one = round(1.0 / (time.time() - t0), 4)
+        torch.set_num_threads(cores)
+    return {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "single_thread_value": one, "parity": parity,
+            "sample": "oracle/picnet_cpu.py train_step at %dx%d, fp32, bs=1 (path has no batch-coupled op), %d warm-up + %d timed steps, median; "
+                      "single_thread_value = one step with torch.set_num_threads(1)" % (size, size, WARM, len(timed))}
 
 
 def main():
@@ -158,6 +203,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 / C5 pSp legs appended as 'extra' (N = 1 only)")
     ap.add_argument("--profile-dump", default=None, help="write the per-shape launch table of the profiled step here")
     args = ap.parse_args()
 
@@ -172,7 +218,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("gloo" if os.environ.get("FMI_REHEARSAL_ONE_GPU") else "nccl")  # "nccl" = RCCL over xGMI
+        if os.environ.get("FMI_REHEARSAL_ONE_GPU"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" = RCCL over xGMI; device_id binds the communicator to this rank's GPU
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from face_mask_inpaint_amd import functional as FF
@@ -237,12 +286,24 @@ def main():
         ach = dom_fl / (dom_ms * 1e-3) / 1e12
         kernel_names = {"attn_fused_bwd": "attn_bwd2_kernel<64,8> (csrc/attention.hip: fused softmax(QQ^T)V backward, fp32 MFMA)",
                         "attn_fused_fwd": "attn_fwd_kernel<64,8> (csrc/attention.hip)"}
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dom_key),
-                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/round1_pmc_attention.json)",
+        traffic, traffic_note = pmc_traffic(dom_key)
+        # SURVEY.md 8(d) prices the attention backward at 2 x the forward's 2 N T^2 (d + C); the flash-style backward also RECOMPUTES
+        # the q q^T product (2 N T^2 (3 d + 2 C) executed): "frac" uses the 8(d) count, "frac_with_recompute" the executed one
+        survey_fl = dom_fl
+        if dom_tag == "attn_fused_bwd":
+            import re
+
+            mm = re.match(r"T(\d+) d(\d+) C(\d+) b(\d+)", dom_key.split("|")[-1])
+            t_, d_, c_, b_ = (int(v) for v in mm.groups())
+            survey_fl = dom_n * 4.0 * b_ * t_ * t_ * (d_ + c_)
+        ach8d = survey_fl / (dom_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach8d, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach8d / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, **traffic_note,
+                    "flop_count": "SURVEY.md 8(d): backward = 2 x forward = 4 N T^2 (d + C)" if survey_fl != dom_fl else "2 M N K per launch",
+                    "achieved_with_recompute": round(ach, 2), "frac_with_recompute": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                     "kernel": kernel_names.get(dom_tag, "gemm_mfma_f32_kernel<...> call site " + dom_tag), "shape": dom_key.split("|")[-1],
                     "launches_per_step": dom_n, "avg_launch_ms": round(dom_ms / dom_n, 3),
-                    "algorithmic_tflop_per_launch": round(dom_fl / dom_n / 1e12, 4),
+                    "algorithmic_tflop_per_launch": round(survey_fl / dom_n / 1e12, 4),
                     "mfma_family": {"achieved": round(fam, 2), "frac": round(fam / FP32_MFMA_PEAK_TFLOPS, 4), "launches": len(recs),
                                     "kernel_ms_per_step": round(tot_ms, 2), "algorithmic_tflop_per_step": round(tot_fl / 1e12, 3)},
                     "by_call_site": {k: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None, "ms": round(v[1], 2), "launches": v[2]}
@@ -251,6 +312,22 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.size)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        # BASELINE configs[2] (C3) and the single-GPU leg of configs[4] (C5), so that the driver's fixed command times them too
+        del G, D, gopt, batch
+        torch.cuda.empty_cache()
+        import bench_psp
+
+        extra = bench_psp.extra_block(dev)
+    collectives = None
+    if world > 1:
+        import torch.distributed as dist
+
+        mine = torch.tensor([getattr(o, "collectives", 0) for o in (gopt.optimizer_G, gopt.optimizer_D)], device=dev, dtype=torch.int64)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        collectives = {"per_rank_G_D_over_%d_steps" % (args.steps + args.warmup + (0 if args.no_roofline else 1)): [c.tolist() for c in allc]}
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -261,7 +338,9 @@ def main():
                "config": {"workload": "train_reference_fill.py PICNet-ref %dx%d fp32, bs=%d per GPU, synthetic CelebA-HQ-shaped batch + random binary_map (BASELINE configs[1]%s)"
                                       % (args.size, args.size, args.batch, "; configs[3] = bs 64 over 8 GPUs" if world == 8 else ""),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        if collectives is not None:
+            out["collectives"] = collectives
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -113,6 +113,80 @@ def native_op_bandwidth(dev):
     return out
 
 
+LOSS_ARGS = dict(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0, w_norm_lambda=0.005,
+                 start_from_latent_avg=True)
+
+
+def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None):
+    """one train_psp.py step loop (train_psp.py:307-335): pSp forward (GradualStyleEncoder on src + ref with attention, StyleGAN2
+    decoder of ``size``), pSpLoss, backward, fused Adam over the encoder (+ decoder when train_decoder, as scripts/train_psp.sh runs
+    it).  Returns (seconds for ``steps`` steps, per-launch summary of one extra profiled step)."""
+    from face_mask_inpaint_amd import functional as FF
+    from face_mask_inpaint_amd.modules.psp.criteria import pSpLoss
+    from face_mask_inpaint_amd.modules.psp.psp import pSp
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    torch.manual_seed(0)
+    opts = types.SimpleNamespace(output_size=size, encoder_type="GradualStyleEncoder", train_decoder=train_decoder, use_attention=True, pt_ckpt_path=None,
+                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype=decoder_dtype)
+    net = pSp(opts).to(dev).train()
+    net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
+    crit = pSpLoss(types.SimpleNamespace(**(loss_args or LOSS_ARGS)))
+    if hasattr(crit, "to"):
+        crit = crit.to(dev)
+    params = [p for p in net.encoder.parameters() if p.requires_grad]
+    if train_decoder:
+        params += [p for p in net.decoder.parameters() if p.requires_grad]
+    opt = FusedAdam(params, lr=1e-4)
+    x, ref, y, m = synth(batch, dev)
+
+    def step():
+        y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True)
+        loss, _, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).item()
+    FF.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    recs, FF.PROFILE = FF.PROFILE, None
+    del net, opt, crit
+    torch.cuda.empty_cache()
+    bf16 = decoder_dtype in ("bf16", torch.bfloat16)
+    summ = summarise(recs, BF16_MFMA_PEAK, only_bf16=True) if bf16 else summarise(recs)
+    return dt, summ
+
+
+def extra_block(dev, steps=4, warmup=2):
+    """what bench.py appends to its JSON line so that the driver's fixed command also times BASELINE configs[2] (C3) and the single-GPU
+    leg of configs[4] (C5): the train_psp step with the bf16 decoder -- images/s, ModulatedConv2d bf16 TFLOP/s inside that step (all
+    bf16 convolution launches of one step: forward, adjoint, weight gradient) against the 2516.6 TFLOP/s dense bf16 peak, the
+    in-decoder upfirdn2d (Blur / RGB-skip Upsample, forward + backward) and fused noise+bias+lrelu in GB/s against 8 TB/s"""
+    out = {}
+    for key, size, batch in (("C3_train_psp_256_bf16_bs16", 256, 16), ("C5_train_psp_1024_bf16_bs4_single_gpu_leg", 1024, 4)):
+        dt, summ = train_leg(dev, "bf16", size, batch, steps, warmup, train_decoder=True)
+        mf = summ.get("mfma", {})
+        out[key] = {"images_per_s": round(batch * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
+                    "modulated_conv_bf16": {"tflops": mf.get("tflops"), "frac_of_bf16_peak": mf.get("utilisation"), "launches": mf.get("launches"),
+                                            "kernel_ms": mf.get("kernel_ms"), "algorithmic_tflop": mf.get("algorithmic_tflop")},
+                    "upfirdn2d_in_decoder": summ.get("upfirdn2d"), "noise_bias_act": summ.get("noise_bias_act"),
+                    "config": "train_psp.py RefpSp + attention (IR-SE50 encoder fp32 on src + ref), StyleGAN2 %d^2 decoder bf16 (fp32 accumulate / master weights), "
+                              "bs %d, --train_decoder 1 as scripts/train_psp.sh, masked-L2 + reference-L2 + W-norm loss (LPIPS / ID off), fused Adam; %d timed steps" % (size, batch, steps)}
+    out["peaks"] = {"bf16_mfma_tflops": BF16_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -127,44 +201,8 @@ def main():
     from face_mask_inpaint_amd.modules.psp.psp import pSp
     from face_mask_inpaint_amd.optim import FusedAdam
 
-    def train_leg(decoder_dtype):
-        torch.manual_seed(0)
-        opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
-                                     stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype=decoder_dtype)
-        net = pSp(opts).to(dev).train()
-        net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
-        crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
-                                             w_norm_lambda=0.005, start_from_latent_avg=True))
-        opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
-        x, ref, y, m = synth(args.batch, dev)
-
-        def step():
-            y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True)
-            loss, _, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
-            return loss
-
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert torch.isfinite(loss).item()
-        FF.PROFILE = []
-        step()
-        torch.cuda.synchronize()
-        recs, FF.PROFILE = FF.PROFILE, None
-        del net, opt
-        torch.cuda.empty_cache()
-        return dt, summarise(recs)
-
-    dt, whole = train_leg("fp32")
-    dt16, whole16 = train_leg("bf16")
+    dt, whole = train_leg(dev, "fp32", 256, args.batch, args.steps, args.warmup, train_decoder=False)
+    dt16, whole16 = train_leg(dev, "bf16", 256, args.batch, args.steps, args.warmup, train_decoder=False)
     out = {"metric": "train_psp images/sec (fp32, encoder trained, decoder frozen, LPIPS/ID off)", "value": round(args.batch * args.steps / dt, 2), "unit": "images/s",
            "n_gpus": 1, "batch": args.batch, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 2), "dtype": "f32", "data": "synthetic",
            "whole_step": whole,

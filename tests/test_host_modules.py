@@ -147,3 +147,26 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert c.fmi_upfirdn2d_f32(p, p, p, 1, 2, 2, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == BAD                     # output would be empty
     c.fmi_avgpool_f32.argtypes = [vp, vp] + [ctypes.c_int] * 5 + [vp]
     assert c.fmi_avgpool_f32(p, p, 1, 4, 4, 4, 8, None) == BAD                                                 # window larger than the image
+
+
+def test_pmc_traffic_profile_is_current():
+    """bench.py's roofline.traffic comes from profiles/pmc_traffic.json; every entry names the kernel it was collected on, the raw
+    PMC summary it was taken from and the sha256 of the kernel's source at that time.  A kernel edited after its PMC pass makes the
+    number stale: this test fails (and bench.py reports traffic = null with the reason) until the pass is repeated."""
+    import hashlib
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tab = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert tab, "no PMC traffic entries"
+    for key, ent in tab.items():
+        src = os.path.join(root, ent["source"])
+        assert hashlib.sha256(open(src, "rb").read()).hexdigest() == ent["source_sha256"], \
+            f"{key}: {ent['source']} changed since {ent['profile']} was collected -- repeat the rocprofv3 --pmc passes (tools/bench_tools/pmc_collect.sh)"
+        raw = json.load(open(os.path.join(root, ent["profile"])))
+        names = {e["kernel"] for sect in ("fetch", "write") for e in raw[sect]}
+        assert ent["kernel"] in names, f"{key}: kernel {ent['kernel']!r} is not in {ent['profile']}"
+        fetch = [e["mean_value"] for e in raw["fetch"] if e["kernel"] == ent["kernel"]][0]
+        write = [e["mean_value"] for e in raw["write"] if e["kernel"] == ent["kernel"]][0]
+        assert abs(fetch - ent["fetch_kb"]) < 1e-3 * fetch and abs(write - ent["write_kb"]) < 1e-3 * max(write, 1.0)
