@@ -80,6 +80,12 @@ SIGNATURES = {
     "fmi_avgpool_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_avgpool_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
     "fmi_maxpool2_f32": [vp, vp, i32, i32, i32, i32, vp],
+    "fmi_adaptive_avgpool_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_adaptive_avgpool_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_maxpool_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_maxpool_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "fmi_argmax_channels_f32": [vp, vp, i64, i32, vp],
+    "fmi_copy_channels_f32": [vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "fmi_maxpool2_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],

@@ -392,3 +392,28 @@ extern "C" int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, 
 extern "C" int fmi_bias_grad_nchw_bf16(const void* g, int N, int C, int64_t HW, float* dbias, void* stream) {
   return bias_grad_nchw_launch((const uint16_t*)g, N, C, HW, dbias, stream);
 }
+
+// dst[r][dst_c0 + j] = src[r][src_c0 + j], j < c: channel slices and concatenations of NHWC maps (model.py:106 return_zq,
+// unet_parts.py:70 torch.cat, example_guided_att.py:37) without a detour through a temporary
+__global__ void __launch_bounds__(256) copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows,
+                                                            int sstride, int sc0, int dstride, int dc0, int c, int vec) {
+  const int cv = c / vec;
+  const int64_t total = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cv;
+    const int j = (int)(i % cv) * vec;
+    if (vec == 4)
+      *reinterpret_cast<float4*>(dst + r * dstride + dc0 + j) = *reinterpret_cast<const float4*>(src + r * sstride + sc0 + j);
+    else
+      dst[r * dstride + dc0 + j] = src[r * sstride + sc0 + j];
+  }
+}
+extern "C" int fmi_copy_channels_f32(const float* src, float* dst, int64_t rows, int src_stride, int src_c0, int dst_stride, int dst_c0,
+                                     int c, void* stream) {
+  if (!src || !dst || rows <= 0 || c <= 0 || src_c0 < 0 || dst_c0 < 0 || src_c0 + c > src_stride || dst_c0 + c > dst_stride) return FMI_ERR_BAD_ARG;
+  const bool v4 = !((src_stride | src_c0 | dst_stride | dst_c0 | c) & 3) && !(((uintptr_t)src | (uintptr_t)dst) & 15);
+  const int vec = v4 ? 4 : 1;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(fmi_bw_grid(rows * (c / vec), 256)), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
+                     src_stride, src_c0, dst_stride, dst_c0, c, vec);
+  return fmi_launch_status();
+}

@@ -268,3 +268,159 @@ extern "C" int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, in
                      OW, ch_std, total);
   return fmi_launch_status();
 }
+
+// ---- nn.AdaptiveAvgPool2d for ANY input / output size (model.py:79 on a 218 x 178 decoder output, id_loss.py:19: 188 -> 112) ----
+// window of output i along an axis of length L -> OL: [floor(i L / OL), ceil((i + 1) L / OL)); windows overlap when L % OL != 0 and
+// have length 1 (replication) when OL > L.  One thread per output element (vectorised over channels when C % 4 == 0).
+__device__ __forceinline__ int aap_lo(int i, int L, int OL) { return (int)(((int64_t)i * L) / OL); }
+__device__ __forceinline__ int aap_hi(int i, int L, int OL) { return (int)(((int64_t)(i + 1) * L + OL - 1) / OL); }
+template <int V>
+__global__ void __launch_bounds__(256) adaptive_avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int OH,
+                                                               int OW, int CV, int64_t total) {
+  typedef typename VecT<V>::T T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % CV);
+    int64_t r = i / CV;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int y0 = aap_lo(oy, H, OH), y1 = aap_hi(oy, H, OH), x0 = aap_lo(ox, W, OW), x1 = aap_hi(ox, W, OW);
+    T s = VecT<V>::zero();
+    for (int a = y0; a < y1; ++a)
+      for (int b = x0; b < x1; ++b) VecT<V>::add(s, reinterpret_cast<const T*>(x)[(((int64_t)n * H + a) * W + b) * CV + c]);
+    VecT<V>::scale(s, 1.f / (float)((y1 - y0) * (x1 - x0)));
+    reinterpret_cast<T*>(y)[i] = s;
+  }
+}
+// gradient: an input pixel gathers from every output window that contains it (at most a handful; candidates around h OL / L)
+template <int V>
+__global__ void __launch_bounds__(256) adaptive_avgpool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int H, int W,
+                                                                   int OH, int OW, int CV, int64_t total) {
+  typedef typename VecT<V>::T T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % CV);
+    int64_t r = i / CV;
+    const int xx = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int n = (int)(r / H);
+    // outputs whose window contains yy: lo(o) <= yy < hi(o); lo is non-decreasing in o, so scan from the first candidate
+    int oy0 = (int)(((int64_t)yy * OH) / H);
+    while (oy0 > 0 && aap_hi(oy0 - 1, H, OH) > yy) --oy0;
+    int ox0 = (int)(((int64_t)xx * OW) / W);
+    while (ox0 > 0 && aap_hi(ox0 - 1, W, OW) > xx) --ox0;
+    T s = VecT<V>::zero();
+    for (int oy = oy0; oy < OH && aap_lo(oy, H, OH) <= yy; ++oy) {
+      if (aap_hi(oy, H, OH) <= yy) continue;
+      const int hy = aap_hi(oy, H, OH) - aap_lo(oy, H, OH);
+      for (int ox = ox0; ox < OW && aap_lo(ox, W, OW) <= xx; ++ox) {
+        if (aap_hi(ox, W, OW) <= xx) continue;
+        const int hx = aap_hi(ox, W, OW) - aap_lo(ox, W, OW);
+        T v = reinterpret_cast<const T*>(gy)[(((int64_t)n * OH + oy) * OW + ox) * CV + c];
+        VecT<V>::scale(v, 1.f / (float)(hy * hx));
+        VecT<V>::add(s, v);
+      }
+    }
+    reinterpret_cast<T*>(gx)[i] = s;
+  }
+}
+extern "C" int fmi_adaptive_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  const bool v4 = C % 4 == 0 && al16(x) && al16(y);
+  const int64_t total = (int64_t)N * OH * OW * (v4 ? C / 4 : C);
+  if (v4)
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<4>, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, OH, OW, C / 4, total);
+  else
+    hipLaunchKernelGGL(adaptive_avgpool_kernel<1>, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, OH, OW, C, total);
+  return fmi_launch_status();
+}
+extern "C" int fmi_adaptive_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW, void* stream) {
+  if (!gy || !gx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  const bool v4 = C % 4 == 0 && al16(gy) && al16(gx);
+  const int64_t total = (int64_t)N * H * W * (v4 ? C / 4 : C);
+  if (v4)
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<4>, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, OH, OW, C / 4, total);
+  else
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<1>, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, OH, OW, C, total);
+  return fmi_launch_status();
+}
+
+// ---- nn.MaxPool2d(k, stride) without padding, floor mode (LPIPS' AlexNet trunk: k 3 stride 2, criteria/lpips/networks.py) ----
+// forward also records the flat window position of the FIRST maximum (torch's tie rule) so that the backward is a gather-free scatter
+__global__ void __launch_bounds__(256) maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ arg,
+                                                      int H, int W, int C, int OH, int OW, int k, int stride, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int a = 0; a < k; ++a)
+      for (int b = 0; b < k; ++b) {
+        const float v = x[(((int64_t)n * H + oy * stride + a) * W + ox * stride + b) * C + c];
+        if (v > best || v != v) {  // ATen's rule: a later NaN replaces the running maximum
+          best = v;
+          bi = a * k + b;
+        }
+      }
+    y[i] = best;
+    if (arg) arg[i] = bi;
+  }
+}
+// windows overlap when stride < k, so the scatter uses atomics (gx zeroed by the caller)
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restrict__ gy, const int32_t* __restrict__ arg,
+                                                          float* __restrict__ gx, int H, int W, int C, int OH, int OW, int k, int stride,
+                                                          int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int bi = arg[i];
+    atomicAdd(gx + (((int64_t)n * H + oy * stride + bi / k) * W + ox * stride + bi % k) * C + c, gy[i]);
+  }
+}
+extern "C" int fmi_maxpool_f32(const float* x, float* y, int32_t* argmax, int N, int H, int W, int C, int k, int stride, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || k <= 0 || stride <= 0 || H < k || W < k) return FMI_ERR_BAD_ARG;
+  const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
+  const int64_t total = (int64_t)N * OH * OW * C;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, H, W, C, OH, OW, k, stride, total);
+  return fmi_launch_status();
+}
+extern "C" int fmi_maxpool_bwd_f32(const float* gy, const int32_t* argmax, float* gx, int N, int H, int W, int C, int k, int stride,
+                                   void* stream) {
+  if (!gy || !argmax || !gx || N <= 0 || C <= 0 || k <= 0 || stride <= 0 || H < k || W < k) return FMI_ERR_BAD_ARG;
+  const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
+  const int64_t total = (int64_t)N * OH * OW * C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, argmax, gx, H, W, C, OH, OW, k, stride, total);
+  return fmi_launch_status();
+}
+
+// ---- argmax over the channel axis of an NHWC map, written as a float mask (PICNet_inference.py:100-101:
+// mask_detector(src, 'train').argmax(1).float()); index work: the FIRST maximum wins like torch.argmax, bit exact ----
+__global__ void __launch_bounds__(256) argmax_channels_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int64_t pixels) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+    const float* row = x + p * C;
+    float best = row[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = row[c];
+      if (v > best || (v != v && best == best)) {  // NaN counts as the maximum (torch.argmax)
+        best = v;
+        bi = c;
+      }
+    }
+    out[p] = (float)bi;
+  }
+}
+extern "C" int fmi_argmax_channels_f32(const float* x, float* out, int64_t pixels, int C, void* stream) {
+  if (!x || !out || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(argmax_channels_kernel, dim3(fmi_bw_grid(pixels, 256)), dim3(256), 0, (hipStream_t)stream, x, out, C, pixels);
+  return fmi_launch_status();
+}

@@ -687,6 +687,73 @@ def avg_pool(x, k=2):
     return _AvgPool.apply(x, k)
 
 
+class _AdaptiveAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        _chk(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        _L().adaptive_avgpool_f32(_p(x), _p(y), n, h, w, c, oh, ow, _st())
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        _L().adaptive_avgpool_bwd_f32(_p(g.contiguous()), _p(gx), n, h, w, c, g.shape[1], g.shape[2], _st())
+        return gx, None, None
+
+
+def adaptive_avg_pool(x, oh, ow):
+    """nn.AdaptiveAvgPool2d((oh, ow)) on NHWC for any sizes; integer down-sampling factors take the k x k kernel"""
+    n, h, w, c = x.shape
+    if (h, w) == (oh, ow):
+        return x
+    if h % oh == 0 and w % ow == 0 and h // oh == w // ow:
+        return avg_pool(x, h // oh)
+    return _AdaptiveAvgPool.apply(x, int(oh), int(ow))
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, stride):
+        _chk(x)
+        n, h, w, c = x.shape
+        oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
+        y = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.float32)
+        arg = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.int32)
+        _L().maxpool_f32(_p(x), _p(y), C.c_void_p(arg.data_ptr()), n, h, w, c, k, stride, _st())
+        ctx.save_for_backward(arg)
+        ctx.cfg = (x.shape, k, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        (n, h, w, c), k, stride = ctx.cfg
+        gx = torch.zeros((n, h, w, c), device=g.device, dtype=torch.float32)
+        _L().maxpool_bwd_f32(_p(g.contiguous()), C.c_void_p(arg.data_ptr()), _p(gx), n, h, w, c, k, stride, _st())
+        return gx, None, None
+
+
+def max_pool(x, k, stride):
+    """nn.MaxPool2d(k, stride) (no padding, floor mode) on NHWC"""
+    if k == 2 and stride == 2 and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0:
+        return max_pool2(x)
+    return _MaxPool.apply(x, int(k), int(stride))
+
+
+def argmax_channels(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """x [N,H,W,C] -> float mask [N,H,W] = argmax over C (first maximum wins): mask_detector(...).argmax(1).float(),
+    PICNet_inference.py:100-101; index work, bit exact, no gradient"""
+    x = x_nhwc.detach()
+    _chk(x)
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    _L().argmax_channels_f32(_p(x), _p(out), out.numel(), x.shape[-1], _st())
+    return out
+
+
 class _MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -802,6 +869,60 @@ class _MaskMul(torch.autograd.Function):
 def mask_mul(x, m, invert=False):
     """x[N,H,W,C] * m[N,H,W] (or 1-m)."""
     return _MaskMul.apply(x, m, 1 if invert else 0)
+
+
+class _SliceChannels(torch.autograd.Function):
+    """x[..., c0:c0 + c] as a contiguous tensor (strided copy kernel); the gradient is written into a zeroed full-width tensor"""
+
+    @staticmethod
+    def forward(ctx, x, c0, c):
+        _chk(x)
+        ctot = x.shape[-1]
+        y = torch.empty(x.shape[:-1] + (c,), device=x.device, dtype=torch.float32)
+        _L().copy_channels_f32(_p(x), _p(y), x.numel() // ctot, ctot, c0, c, 0, c, _st())
+        ctx.cfg = (x.shape, c0, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, c0, c = ctx.cfg
+        gx = torch.zeros(shape, device=g.device, dtype=torch.float32)
+        _L().copy_channels_f32(_p(g.contiguous()), _p(gx), g.numel() // c, c, 0, shape[-1], c0, c, _st())
+        return gx, None, None
+
+
+def slice_channels(x, c0, c):
+    return _SliceChannels.apply(x, int(c0), int(c))
+
+
+class _CatChannels(torch.autograd.Function):
+    """torch.cat([a, b], dim=-1) of two NHWC maps as two strided copies"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, b)
+        ca, cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // ca
+        y = torch.empty(a.shape[:-1] + (ca + cb,), device=a.device, dtype=torch.float32)
+        _L().copy_channels_f32(_p(a), _p(y), rows, ca, 0, ca + cb, 0, ca, _st())
+        _L().copy_channels_f32(_p(b), _p(y), rows, cb, 0, ca + cb, ca, cb, _st())
+        ctx.cfg = (ca, cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb = ctx.cfg
+        g = g.contiguous()
+        rows = g.numel() // (ca + cb)
+        ga = torch.empty(g.shape[:-1] + (ca,), device=g.device, dtype=torch.float32)
+        gb = torch.empty(g.shape[:-1] + (cb,), device=g.device, dtype=torch.float32)
+        _L().copy_channels_f32(_p(g), _p(ga), rows, ca + cb, 0, ca, 0, ca, _st())
+        _L().copy_channels_f32(_p(g), _p(gb), rows, ca + cb, ca, cb, 0, cb, _st())
+        return ga, gb
+
+
+def cat_channels(a, b):
+    return _CatChannels.apply(a.contiguous(), b.contiguous())
 
 
 def binarise_mask(mask_i64: torch.Tensor) -> torch.Tensor:

@@ -21,7 +21,7 @@ class ReferenceFill(nn.Module):
         self.mask_detector = mask_detector
         self.encoder_type = encoder_params.pop("type")
         if self.encoder_type != "pluralistic":
-            raise NotImplementedError("only encoder type 'pluralistic' is on the hot path (DRN: SURVEY.md section 2 row 14)")
+            raise NotImplementedError("encoder type 'drn' (modules/drn.py) is not built: BASELINE configs use 'pluralistic'")
         self.src_encoder = network.define_e(**encoder_params, encoder_type="src")
         self.ref_encoder = network.define_e(**encoder_params, encoder_type="ref")
         self.decoder = network.define_g(**decoder_params)
@@ -33,13 +33,16 @@ class ReferenceFill(nn.Module):
 
     def forward(self, src_image, ref_image, src_mask=None, resize=True, no_prior=False, eps=None):
         """src_image / ref_image [N,3,H,W]; src_mask [N,H,W] float {0,1}.  ``eps = (eps_p, eps_q)`` optionally injects
-        the two standard-normal draws of get_z ([N, z_nc, h, w], posterior first); default: fresh torch.randn draws."""
+        the two standard-normal draws of get_z ([N, z_nc, h, w], posterior first); default: fresh torch.randn draws.
+        Variants of model.py:97-112: ``use_att=False`` blends the two feature maps with the rescaled mask and decodes from z_q
+        alone; ``no_prior=True`` (what PICNet_inference.py:107 passes for --old_model) decodes without z and rescales the image to
+        218 x 178 with scale_img instead of pooling."""
         if src_mask is None:
             if self.mask_detector is None:
                 raise ValueError("src_mask is required when no mask_detector is attached")
-            src_mask = self.mask_detector(src_image, mode="eval")
-        if no_prior or not self.use_att:
-            raise NotImplementedError("no_prior / use_att=False variants are not on the benchmarked path")
+            # model.py:86 feeds the detector's boolean [N, 2, H, W] output to scale_img, which fails in the reference as well
+            # (F.interpolate of a 5-D bool tensor); the working call sites pass argmax masks (PICNet_inference.py:100-101)
+            src_mask = self.mask_detector.predict_mask(src_image)
         with weight_scope(self):
             src = FF.to_nhwc(src_image)
             ref = FF.to_nhwc(ref_image)
@@ -47,20 +50,26 @@ class ReferenceFill(nn.Module):
             o_ref, ref_feat = self.ref_encoder.nhwc_raw(ref)
             n, fh, fw, _ = src_feat.shape
             m = FF.resize_bilinear(src_mask.contiguous().unsqueeze(-1), fh, fw).view(n, fh, fw)
-            enc = self.attention.nhwc(m, src_feat, ref_feat)
-            z_nc = o_src.shape[-1] // 2
-            if eps is None:
-                eps_p = torch.randn((n, fh, fw, z_nc), device=src.device)
-                eps_q = torch.randn((n, fh, fw, z_nc), device=src.device)
+            if self.use_att:
+                enc = self.attention.nhwc(m, src_feat, ref_feat)
+            else:  # (1 - m) * src + m * ref  (model.py:100-101)
+                enc = FF.add(FF.mask_mul(src_feat, m, True), FF.mask_mul(ref_feat, m, False))
+            if no_prior:
+                img = self.decoder.nhwc(enc, None)
             else:
-                eps_p, eps_q = FF.to_nhwc(eps[0]), FF.to_nhwc(eps[1])
-            z = FF.vae_sample(o_src, o_ref, eps_q, eps_p)
-            img = self.decoder.nhwc(enc, z)
+                z_nc = o_src.shape[-1] // 2
+                if eps is None:
+                    eps_p = torch.randn((n, fh, fw, z_nc), device=src.device)
+                    eps_q = torch.randn((n, fh, fw, z_nc), device=src.device)
+                else:
+                    eps_p, eps_q = FF.to_nhwc(eps[0]), FF.to_nhwc(eps[1])
+                z = FF.vae_sample(o_src, o_ref, eps_q, eps_p)  # [z_q, z_p] along channels
+                if not self.use_att:  # get_z(..., return_zq=True): the prior sample alone (model.py:106)
+                    z = FF.slice_channels(z, 0, z_nc)
+                img = self.decoder.nhwc(enc, z)
             if resize:
-                oh, ow = self._out_size
-                ih, iw = img.shape[1], img.shape[2]
-                if ih % oh or iw % ow or ih // oh != iw // ow:
-                    raise NotImplementedError("AdaptiveAvgPool2d is implemented for integer pooling factors (1024 -> 256)")
-                if ih // oh > 1:
-                    img = FF.avg_pool(img, ih // oh)
+                if no_prior:
+                    img = FF.resize_bilinear(img, 218, 178)  # scale_img(dec_image, (218, 178)), model.py:109-110
+                else:
+                    img = FF.adaptive_avg_pool(img, *self._out_size)
             return FF.to_nchw(img)

@@ -278,6 +278,21 @@ int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const float* o_r
 /* k x k mean pooling, stride k (nn.AvgPool2d(2,2) base_function.py:233; AdaptiveAvgPool2d 1024->256 model.py:79) */
 int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
 int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream);
+/* dst[r][dst_c0 + j] = src[r][src_c0 + j] for j < c: channel slice / concatenation of NHWC maps (model.py:106 return_zq;
+ * unet_parts.py:70 and example_guided_att.py:37 torch.cat) */
+int fmi_copy_channels_f32(const float* src, float* dst, int64_t rows, int src_stride, int src_c0, int dst_stride, int dst_c0, int c,
+                          void* stream);
+/* nn.AdaptiveAvgPool2d for any input / output size (model.py:79,111 on non-1024 decoder outputs; psp.py:33 on outputs smaller than
+ * 256; id_loss.py:19 188 -> 112): window i of an axis = [floor(i L / OL), ceil((i + 1) L / OL)).  NHWC. */
+int fmi_adaptive_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream);
+int fmi_adaptive_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW, void* stream);
+/* nn.MaxPool2d(k, stride), no padding, floor mode (criteria/lpips/networks.py: AlexNet trunk k 3 stride 2); argmax[N,OH,OW,C]
+ * (may be NULL) = window position of the first maximum; the backward scatters with atomics, caller zeroes gx */
+int fmi_maxpool_f32(const float* x, float* y, int32_t* argmax, int N, int H, int W, int C, int k, int stride, void* stream);
+int fmi_maxpool_bwd_f32(const float* gy, const int32_t* argmax, float* gx, int N, int H, int W, int C, int k, int stride, void* stream);
+/* out[p] = (float) argmax_c x[p][c] (first maximum wins, NaN is the maximum): PICNet_inference.py:100-101
+ * mask_detector(src, 'train').argmax(1).float(); bit exact */
+int fmi_argmax_channels_f32(const float* x, float* out, int64_t pixels, int C, void* stream);
 /* 2x2 max pooling (VGG16 features, loss.py:21-25); backward routes to the first maximum */
 int fmi_maxpool2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int fmi_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C, void* stream);

@@ -677,3 +677,172 @@ def psp_whole_fixture():
 if __name__ == "__main__":
     generator_fixture()
     psp_whole_fixture()
+
+
+def picnet_variants_fixture():
+    """ReferenceFill's other call forms (model.py:97-112) and the inference harness (PICNet_inference.py:88-109) from the imported
+    reference: use_att=False (mask blend + z_q only) with backward, no_prior=True (--old_model: no z, 218 x 178 output), a
+    non-integer AdaptiveAvgPool2d, the UNet MaskDetector (seeded parameters, eval-mode BatchNorm, odd sizes -> the pad branch of
+    Up) and infer_batch itself.  PICNet_inference.py imports pytorch_msssim and dataloader.py imports torchvision.transforms at
+    module level; both are absent here and irrelevant to infer_batch, so empty stand-in modules satisfy the import."""
+    ref_model, ref_loss, ref_network = import_reference()
+    import torch.distributions.normal as tdn
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from seeded import grad_digest, seeded_fill_, seeded_tensor
+
+    for name, attrs in (("pytorch_msssim", ("SSIM", "MS_SSIM")), ("torchvision.transforms", ("Normalize",))):
+        m = types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, type(a, (), {"__init__": lambda self, *a_, **k_: None}))
+        sys.modules.setdefault(name, m)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import PICNet_inference as PI
+    from modules.mask_detector import MaskDetector
+
+    g = torch.Generator().manual_seed(61)
+    fx = {}
+    old = tdn._standard_normal
+
+    def run(G, src, ref, mask, **kw):
+        feeder = EpsFeeder(int(torch.randint(0, 10000, (1,), generator=g)))
+        tdn._standard_normal = feeder
+        try:
+            out = G(src, ref, src_mask=mask, **kw)
+        finally:
+            tdn._standard_normal = old
+        return out, feeder.draws
+
+    torch.manual_seed(19)
+    enc = dict(type="pluralistic", ngf=8, z_nc=8, img_f=16, layers=5, norm="none", activation="LeakyReLU", L=2)
+    src, ref = torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 3, 64, 64, generator=g)
+    mask = (torch.rand(2, 64, 64, generator=g) < 0.4).float()
+    # ---- use_att=False: decoder sees img_f channels and z_q only
+    G = ref_model.ReferenceFill(None, dict(enc), dict(ngf=8, z_nc=8, img_f=16, layers=5, norm="instance", activation="LeakyReLU", L=0),
+                                use_att=False, out_size=(64, 64))
+    sd0 = sd_clone(G)
+    out, draws = run(G, src, ref, mask)
+    w = torch.randn(out.shape, generator=g)
+    (out * w).sum().backward()
+    fx["no_att"] = dict(sd0=sd0, uv1={k: v for k, v in sd_clone(G).items() if k.endswith("weight_u") or k.endswith("weight_v")}, src=src, ref=ref, mask=mask, eps_p=draws[0], eps_q=draws[1], out=out.detach().clone(), gout=w,
+                        gparams={n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None})
+    # ---- use_att=True: no_prior (218 x 178 output), resize=False, non-integer pooling
+    dec = dict(ngf=8, z_nc=16, img_f=32, layers=5, norm="instance", activation="LeakyReLU", L=0)
+    G = ref_model.ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(100, 90))
+    with torch.no_grad():
+        G.decoder.attn1.gamma.fill_(0.3)
+    sd0 = sd_clone(G)
+    with torch.no_grad():
+        o_np, _ = run(G, src, ref, mask, no_prior=True)
+        sd_a = sd_clone(G)
+        o_raw, d_raw = run(G, src, ref, mask, resize=False)
+        sd_b = sd_clone(G)
+    o_pool, d_pool = run(G, src, ref, mask)
+    w = torch.randn(o_pool.shape, generator=g)
+    (o_pool * w).sum().backward()
+    uv = lambda sd: {k: v for k, v in sd.items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    fx["variants"] = dict(sd0=sd0, src=src, ref=ref, mask=mask, no_prior=o_np, raw=grad_digest(o_raw, 32768), raw_eps=d_raw[:2], pool=o_pool.detach().clone(), pool_eps=d_pool[:2],
+                          gout=w, uv_after_no_prior=uv(sd_a), uv_after_raw=uv(sd_b),
+                          gparams={n: grad_digest(p.grad, 512) for n, p in G.named_parameters() if p.grad is not None})
+    # ---- mask detector (17 M parameters: seeded) and infer_batch
+    md = MaskDetector(n_channels=3, bilinear=True)
+    seeded_fill_(md, 91)
+    md.eval()
+    x = torch.rand(2, 3, 72, 56, generator=g)
+    with torch.no_grad():
+        l0 = md(x, mode="train")
+        # random weights predict one class everywhere: shift the output bias so that ~40 % of the pixels are class 1
+        md.model.outc.conv.bias[1] += torch.quantile((l0[:, 0] - l0[:, 1]).flatten(), 0.6)
+        logits = md(x, mode="train")
+        thr = md(x, mode="eval")
+    fx["mask_detector"] = dict(seed=91, outc_bias=md.model.outc.conv.bias.detach().clone(), x=x, logits=logits, argmax=logits.argmax(1).float(), thresholded=thr)
+    G = ref_model.ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(64, 64))
+    G.load_state_dict(sd0, strict=False)  # the parameters of the "variants" case
+    feeder = EpsFeeder(77)
+    tdn._standard_normal = feeder
+    try:
+        gen, m_out = PI.infer_batch(G, md, (src, ref), torch.device("cpu"))
+    finally:
+        tdn._standard_normal = old
+    fx["infer_batch"] = dict(src=src, ref=ref, gen=gen, mask=m_out, eps_p=feeder.draws[0], eps_q=feeder.draws[1])
+    G.load_state_dict(sd0, strict=False)
+    with torch.no_grad():
+        gen_old, m_old = PI.infer_batch(G, md, (src, ref), torch.device("cpu"), old_model=True)
+    fx["infer_batch"]["gen_old_model"], fx["infer_batch"]["mask_old_model"] = gen_old, m_old
+    torch.save(fx, os.path.join(OUT, "picnet_infer.pt"))
+    print("picnet_infer:", sorted(fx), "%.2f MB" % (os.path.getsize(os.path.join(OUT, "picnet_infer.pt")) / 1e6),
+          "mask fraction", float(fx["mask_detector"]["argmax"].mean()), "no_prior", tuple(o_np.shape), "pool", tuple(o_pool.shape))
+
+
+if __name__ == "__main__":
+    picnet_variants_fixture()
+
+
+def dataset_fixture():
+    """a tiny CelebA-HQ-shaped directory (6 synthetic 48 x 40 jpgs of 3 identities + one singleton identity that must be
+    filtered, ``<id>_surgical.jpg`` sources, ``<id>.npy`` uint8 masks, an identity file) written under tests/golden/dataset/, and
+    what the reference's own ReferenceDataset (dataloader.py:122-266) returns for every item at scale 0.5, with and without
+    apply_transform.  torchvision.transforms.Normalize and pytorch_msssim are absent here: stand-ins (Normalize = (x - m) / s)."""
+    import numpy as np
+    from PIL import Image
+
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.m, self.s = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.m) / self.s
+
+    tvt.Normalize = Normalize
+    sys.modules["torchvision.transforms"] = tvt
+    install_torchvision_stub()
+    sys.modules["torchvision"].transforms = tvt
+    pm = types.ModuleType("pytorch_msssim")
+    pm.SSIM = pm.MS_SSIM = type("SSIM", (), {"__init__": lambda self, *a, **k: None})
+    sys.modules["pytorch_msssim"] = pm
+    sys.modules.pop("dataloader", None)
+    import dataloader as DL
+
+    root = os.path.join(OUT, "dataset")
+    for d in ("images_masked", "images", "binary_map"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    rng = np.random.RandomState(5)
+    ids = ["101", "102", "103", "104", "105", "106", "107"]
+    ident = {"101": 1, "102": 1, "103": 2, "104": 2, "105": 2, "106": 3, "107": 3}
+    ident["108"] = 4  # singleton identity: filtered
+    H, W = 48, 40
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in ids + ["108"]:
+        base = (np.stack([np.sin(xx / (3.0 + int(i) % 5)) * 0.5 + 0.5, np.cos(yy / (2.0 + int(i) % 3)) * 0.5 + 0.5, (xx + yy) / (H + W)], -1) * 255)
+        img = np.clip(base + rng.randn(H, W, 3) * 12, 0, 255).astype(np.uint8)
+        m = (((yy - 30) / 10.0) ** 2 + ((xx - 20) / 14.0) ** 2 <= 1).astype(np.uint8) * 255
+        Image.fromarray(img).save(os.path.join(root, "images", i + ".jpg"), quality=92)
+        sur = img.copy()
+        sur[m > 0] = 200
+        Image.fromarray(sur).save(os.path.join(root, "images_masked", i + "_surgical.jpg"), quality=92)
+        np.save(os.path.join(root, "binary_map", i + ".npy"), m)
+    with open(os.path.join(root, "identity.txt"), "w") as f:
+        for i in ids + ["108"]:
+            f.write(f"{i}.jpg {ident[i]}\n")
+    import random
+
+    fx = {}
+    for tr in (False, True):
+        ds = DL.ReferenceDataset(os.path.join(root, "images_masked"), os.path.join(root, "images"), os.path.join(root, "binary_map"),
+                                 os.path.join(root, "identity.txt"), apply_transform=tr, scale=0.5, return_id=True)
+        order = sorted(range(len(ds)), key=lambda j: ds.ids[j])
+        items = []
+        for j in order:
+            random.seed(1000 + int(ds.ids[j]))
+            it = ds[j]
+            items.append({k: v.clone() for k, v in it.items()})
+        fx["transform" if tr else "plain"] = dict(ids=[ds.ids[j] for j in order], items=items)
+    torch.save(fx, os.path.join(OUT, "dataset.pt"))
+    print("dataset:", fx["plain"]["ids"], tuple(fx["plain"]["items"][0]["src_img"].shape), "%.2f MB" % (os.path.getsize(os.path.join(OUT, "dataset.pt")) / 1e6))
+
+
+if __name__ == "__main__":
+    dataset_fixture()

@@ -243,7 +243,8 @@ def scale_img(img: torch.Tensor, size) -> torch.Tensor:
 def reference_fill_forward(P: Params, src: torch.Tensor, ref: torch.Tensor, src_mask: torch.Tensor,
                            eps_p: torch.Tensor, eps_q: torch.Tensor, *, enc_layers: int = 5, enc_L: int = 6,
                            enc_z_nc: int = 128, dec_layers: int = 5, dec_L: int = 0, out_size=(256, 256),
-                           use_att: bool = True, resize: bool = True) -> torch.Tensor:
+                           use_att: bool = True, resize: bool = True, no_prior: bool = False) -> torch.Tensor:
+    """ReferenceFill.forward (model.py:81-112) incl. its ``use_att=False`` blend and the ``no_prior`` form of --old_model"""
     src_dist, src_feat = res_encoder(P, "src_encoder", src, "src", enc_layers, enc_L, enc_z_nc)
     ref_dist, ref_feat = res_encoder(P, "ref_encoder", ref, "ref", enc_layers, enc_L, enc_z_nc)
     m = scale_img(src_mask.unsqueeze(1), src_feat.shape[-2:])
@@ -251,10 +252,10 @@ def reference_fill_forward(P: Params, src: torch.Tensor, ref: torch.Tensor, src_
         enc = example_guided_attention(P, "attention", m, src_feat, ref_feat)
     else:
         enc = (1 - m) * src_feat + m * ref_feat
-    z = get_z(src_dist, ref_dist, eps_p, eps_q, return_zq=not use_att)
+    z = None if no_prior else get_z(src_dist, ref_dist, eps_p, eps_q, return_zq=not use_att)
     img = res_generator(P, "decoder", enc, z, dec_layers, dec_L)
     if resize:
-        img = F.adaptive_avg_pool2d(img, out_size)
+        img = scale_img(img, (218, 178)) if no_prior else F.adaptive_avg_pool2d(img, out_size)
     return img
 
 
