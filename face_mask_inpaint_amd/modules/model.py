@@ -43,7 +43,10 @@ class ReferenceFill(nn.Module):
             # model.py:86 feeds the detector's boolean [N, 2, H, W] output to scale_img, which fails in the reference as well
             # (F.interpolate of a 5-D bool tensor); the working call sites pass argmax masks (PICNet_inference.py:100-101)
             src_mask = self.mask_detector.predict_mask(src_image)
-        with weight_scope(self):
+        skip = ()
+        if no_prior:  # the decoder's latent blocks do not run without z (network.py:253-260)
+            skip = tuple(getattr(self.decoder, n) for n in ["generator"] + ["generator%d" % i for i in range(self.decoder.L)])
+        with weight_scope(self, skip):
             src = FF.to_nhwc(src_image)
             ref = FF.to_nhwc(ref_image)
             o_src, src_feat = self.src_encoder.nhwc_raw(src)

@@ -20,14 +20,19 @@ from . import functional as FF
 _ACTIVE = [0]
 
 
-def _collect(root: nn.Module) -> List[nn.Module]:
-    cached = getattr(root, "_fmi_weight_list", None)
-    if cached is not None:
-        return cached
+def _collect(root: nn.Module, skip=()) -> List[nn.Module]:
+    key = tuple(sorted(id(m) for m in skip))
+    cache = getattr(root, "_fmi_weight_lists", None)
+    if cache is None:
+        cache = {}
+        object.__setattr__(root, "_fmi_weight_lists", cache)
+    if key in cache:
+        return cache[key]
     out, seen = [], set()
+    skip_ids = set(key)
 
     def walk(m: nn.Module):
-        if getattr(m, "_fmi_never_runs", False):
+        if getattr(m, "_fmi_never_runs", False) or id(m) in skip_ids:
             return
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
             if id(m) not in seen:
@@ -38,21 +43,24 @@ def _collect(root: nn.Module) -> List[nn.Module]:
             walk(ch)
 
     walk(root)
-    object.__setattr__(root, "_fmi_weight_list", out)
+    cache[key] = out
     return out
 
 
 class weight_scope:
-    """``with weight_scope(module):`` -- prepares all conv weights under ``module`` unless an outer scope did."""
+    """``with weight_scope(module):`` -- prepares all conv weights under ``module`` unless an outer scope did.  ``skip``: sub-modules
+    that will NOT run in this forward (e.g. the decoder's latent ResBlocks when ReferenceFill is called with no_prior): their
+    SpectralNorm u / v must stay untouched, as in the reference where a conv's power iteration happens inside its own forward."""
 
-    def __init__(self, root: nn.Module):
+    def __init__(self, root: nn.Module, skip=()):
         self.root = root
+        self.skip = tuple(skip)
         self.owner = False
 
     def __enter__(self):
         if _ACTIVE[0] == 0:
             self.owner = True
-            convs = _collect(self.root)
+            convs = _collect(self.root, self.skip)
             if convs:
                 items = []
                 for c in convs:

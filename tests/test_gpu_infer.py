@@ -75,8 +75,11 @@ def test_reference_fill_without_attention(dev, golden):
     torch.testing.assert_close(out.detach().cpu(), f["out"], rtol=1e-3, atol=1e-5)
     (out * f["gout"].to(dev)).sum().backward()
     P = dict(G.named_parameters())
+    gmax = max(float(g.abs().max()) for g in f["gparams"].values())
     for n, g in f["gparams"].items():
-        lim = 3e-3 * float(g.abs().max()) + 1e-6  # kink flips of this tiny network: see tests/test_gpu_model.py:_check_grads_fp64
+        # 3e-3: kink flips of this tiny network (tests/test_gpu_model.py:_check_grads_fp64); the floor covers gradients that are
+        # analytically zero (a conv bias in front of InstanceNorm) and hold rounding noise of the ~gmax-sized terms on both sides
+        lim = 3e-3 * float(g.abs().max()) + 1e-5 * gmax
         assert float((P[n].grad.cpu() - g).abs().max()) <= lim, n
     sd = G.state_dict()
     for k, v in f["uv1"].items():
@@ -93,7 +96,10 @@ def test_reference_fill_no_prior_raw_and_fractional_pool(dev, golden):
     with torch.no_grad():
         o = G(src, ref, src_mask=mask, no_prior=True)
         assert o.shape == (2, 3, 218, 178)
-        torch.testing.assert_close(o.cpu(), f["no_prior"], rtol=1e-3, atol=1e-5)
+        # without z the first InstanceNorm sees the attention output alone, whose src_att half is nearly constant over space at
+        # initialisation (a soft-max average): its 1 / std amplifies forward rounding ~500x (the CPU oracle itself is 7e-5 from the
+        # reference on another host) -- bounded by north_star's 1e-3 of the activation range, not by per-element rtol
+        torch.testing.assert_close(o.cpu(), f["no_prior"], rtol=0, atol=1e-3 * float(f["no_prior"].abs().max()))
         sd = G.state_dict()
         for k, v in f["uv_after_no_prior"].items():  # the decoder's generator block does not run without z: its u / v stay put
             torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
@@ -104,8 +110,10 @@ def test_reference_fill_no_prior_raw_and_fractional_pool(dev, golden):
     torch.testing.assert_close(o.detach().cpu(), f["pool"], rtol=1e-3, atol=1e-5)
     (o * f["gout"].to(dev)).sum().backward()
     P = dict(G.named_parameters())
+    gmax = max(float(d["max"]) for d in f["gparams"].values())
     for n, d in f["gparams"].items():
-        check_digest(P[n].grad, d, 5e-3, n)
+        if float(d["max"]) > 1e-5 * gmax:  # below: analytically zero (conv bias in front of InstanceNorm), rounding noise on both sides
+            check_digest(P[n].grad, d, 5e-3, n)
 
 
 def test_mask_detector_and_infer_batch(dev, golden):
@@ -127,7 +135,10 @@ def test_mask_detector_and_infer_batch(dev, golden):
         thr = md(m["x"].to(dev), mode="eval")
         am = md.predict_mask(m["x"].to(dev))
     torch.testing.assert_close(logits.cpu(), m["logits"], rtol=1e-3, atol=1e-3)
-    assert torch.equal(am.cpu(), logits.argmax(1).float().cpu())  # the index kernel on the HIP logits: bit exact
+    from face_mask_inpaint_amd import functional as FF
+
+    # the index kernel on THESE logits is bit exact (a second forward may differ in the last bit: split reductions use fp32 atomics)
+    assert torch.equal(FF.argmax_channels(FF.to_nhwc(logits)).cpu(), logits.argmax(1).float().cpu())
     margin = (m["logits"][:, 0] - m["logits"][:, 1]).abs()
     assert torch.equal(am.cpu()[margin > 1e-2], m["argmax"][margin > 1e-2])
     sure = (margin > 1e-2).unsqueeze(1).expand_as(m["thresholded"])
@@ -142,7 +153,7 @@ def test_mask_detector_and_infer_batch(dev, golden):
     gen, mask = infer_batch(G, md, (f["src"], f["ref"]), dev, old_model=True)
     assert gen.shape == (2, 3, 218, 178)
     if torch.equal(mask, f["mask_old_model"]):
-        torch.testing.assert_close(gen.cpu(), f["gen_old_model"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(gen.cpu(), f["gen_old_model"], rtol=0, atol=1e-3 * float(f["gen_old_model"].abs().max()))  # see the no_prior note above
 
 
 def test_c1_harness_runs_at_full_size(dev):
