@@ -86,6 +86,10 @@ SIGNATURES = {
     "fmi_maxpool_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_argmax_channels_f32": [vp, vp, i64, i32, vp],
     "fmi_copy_channels_f32": [vp, vp, i64, i32, i32, i32, i32, i32, vp],
+    "fmi_l2norm_rows_f32": [vp, vp, vp, i64, i32, f32, vp],
+    "fmi_l2norm_rows_bwd_f32": [vp, vp, vp, vp, i64, i32, f32, vp],
+    "fmi_lpips_layer_f32": [vp, vp, vp, vp, i64, i32, f32, vp],
+    "fmi_lpips_layer_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "fmi_maxpool2_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "fmi_resize_bilinear_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_resize_bilinear_bwd_f32": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],

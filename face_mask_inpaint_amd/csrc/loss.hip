@@ -340,3 +340,84 @@ extern "C" int fmi_ssim_f32(const float* img1, const float* img2, const float* w
                      planes_per_out, out_zeroed);
   return fmi_launch_status();
 }
+
+// ---- LPIPS / ArcFace pieces (criteria/lpips/utils.py:6-8 normalize_activation, helpers.py:15-18 l2_norm, lpips.py:30-36) ----
+// one wave per row: y = x / (||x|| + eps); inv[row] = 1 / (||x|| + eps)
+__global__ void __launch_bounds__(256) l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                                          int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) ss += xr[c] * xr[c];
+  ss = wave_sum(ss);
+  const float s = 1.f / (sqrtf(ss) + eps);
+  for (int c = lane; c < C; c += 64) y[row * C + c] = xr[c] * s;
+  if (lane == 0) inv[row] = s;
+}
+// gx = s (g - y (g . y) (n + eps) / n), n = 1 / s - eps; an all-zero row (n = 0: autograd's 0 / 0 in the reference) gets s g
+__global__ void __launch_bounds__(256) l2norm_rows_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const float* __restrict__ inv, float* __restrict__ gx, int64_t rows, int C,
+                                                              float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += g[row * C + c] * y[row * C + c];
+  dot = wave_sum(dot);
+  const float s = inv[row];
+  const float n = 1.f / s - eps;
+  const float k = n > 0.f ? dot * (n + eps) / n : 0.f;
+  for (int c = lane; c < C; c += 64) gx[row * C + c] = s * (g[row * C + c] - y[row * C + c] * k);
+}
+extern "C" int fmi_l2norm_rows_f32(const float* x, float* y, float* inv_norm, int64_t rows, int C, float eps, void* stream) {
+  if (!x || !y || !inv_norm || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, rows, C, eps);
+  return fmi_launch_status();
+}
+extern "C" int fmi_l2norm_rows_bwd_f32(const float* g, const float* y, const float* inv_norm, float* gx, int64_t rows, int C, float eps,
+                                       void* stream) {
+  if (!g || !y || !inv_norm || !gx || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, (hipStream_t)stream, g, y, inv_norm, gx, rows, C, eps);
+  return fmi_launch_status();
+}
+// out[0] += scale * sum_p sum_c w[c] (fx[p][c] - fy[p][c])^2: one LPIPS layer = squared difference, 1x1 "lin" convolution to one
+// channel, spatial mean and the sum over the batch in ONE pass (lpips.py:33-36); per-workgroup partial, one atomic each
+__global__ void __launch_bounds__(256) lpips_layer_kernel(const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ w,
+                                                          float* __restrict__ out, int64_t total, int C, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float d = fx[i] - fy[i];
+    s += w[i % C] * d * d;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) atomicAdd(out, s * scale);
+}
+__global__ void __launch_bounds__(256) lpips_layer_bwd_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
+                                                              const float* __restrict__ w, const float* __restrict__ gout,
+                                                              float* __restrict__ gfx, float* __restrict__ gfy, int64_t total, int C,
+                                                              float scale) {
+  const float k = 2.f * scale * gout[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = k * w[i % C] * (fx[i] - fy[i]);
+    if (gfx) gfx[i] = v;
+    if (gfy) gfy[i] = -v;
+  }
+}
+extern "C" int fmi_lpips_layer_f32(const float* fx, const float* fy, const float* w, float* out, int64_t pixels, int C, float scale,
+                                   void* stream) {
+  if (!fx || !fy || !w || !out || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = pixels * C;
+  int g = fmi_bw_grid(total, 256 * 8);
+  hipLaunchKernelGGL(lpips_layer_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, fx, fy, w, out, total, C, scale);
+  return fmi_launch_status();
+}
+extern "C" int fmi_lpips_layer_bwd_f32(const float* fx, const float* fy, const float* w, const float* gout, float* gfx, float* gfy,
+                                       int64_t pixels, int C, float scale, void* stream) {
+  if (!fx || !fy || !w || !gout || (!gfx && !gfy) || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = pixels * C;
+  hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, fx, fy, w, gout, gfx, gfy, total, C, scale);
+  return fmi_launch_status();
+}

@@ -1184,6 +1184,92 @@ def mse_to_const(a, c0):
     return _ReduceLoss.apply(2, a.contiguous(), None, float(c0), 1.0 / a.numel())
 
 
+class _L2NormRows(torch.autograd.Function):
+    """y = x / (||x|| + eps) over the last dimension"""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _chk(x)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _L().l2norm_rows_f32(_p(x), _p(y), _p(inv), rows, c, eps, _st())
+        ctx.save_for_backward(y, inv)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, inv = ctx.saved_tensors
+        c = y.shape[-1]
+        gx = torch.empty_like(y)
+        _L().l2norm_rows_bwd_f32(_p(g.contiguous()), _p(y), _p(inv), _p(gx), y.numel() // c, c, ctx.eps, _st())
+        return gx, None
+
+
+def l2norm_rows(x, eps=0.0):
+    return _L2NormRows.apply(x.contiguous(), float(eps))
+
+
+class _LpipsLayer(torch.autograd.Function):
+    """scale * sum_p sum_c w[c] (fx - fy)^2 for NHWC feature maps fx, fy [N, H, W, C] (one LPIPS layer, lpips.py:33-36)"""
+
+    @staticmethod
+    def forward(ctx, fx, fy, w, scale):
+        _chk(fx, fy, w)
+        c = fx.shape[-1]
+        out = _zeros((), fx.device, torch.float32)
+        _L().lpips_layer_f32(_p(fx), _p(fy), _p(w), _p(out), fx.numel() // c, c, scale, _st())
+        ctx.save_for_backward(fx, fy, w)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fx, fy, w = ctx.saved_tensors
+        c = fx.shape[-1]
+        gfx = torch.empty_like(fx) if ctx.needs_input_grad[0] else None
+        gfy = torch.empty_like(fy) if ctx.needs_input_grad[1] else None
+        if gfx is not None or gfy is not None:
+            _L().lpips_layer_bwd_f32(_p(fx), _p(fy), _p(w), _p(g.contiguous()), _p(gfx), _p(gfy), fx.numel() // c, c, ctx.scale, _st())
+        return gfx, gfy, None, None
+
+
+def lpips_layer(fx, fy, w, scale):
+    return _LpipsLayer.apply(fx.contiguous(), fy.contiguous(), w.contiguous(), float(scale))
+
+
+class _DotAll(torch.autograd.Function):
+    """scale * sum(a * b) over all elements"""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        _chk(a, b)
+        out = _zeros((), a.device, torch.float32)
+        _L().dot_f32(_p(a), _p(b), a.numel(), scale, _p(out), _st())
+        ctx.save_for_backward(a, b)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        k = g.contiguous().view(1) * ctx.scale
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = torch.empty_like(a)
+            _L().axpy_dev_f32(_p(b), _p(k), None, _p(ga), a.numel(), _st())
+        if ctx.needs_input_grad[1]:
+            gb = torch.empty_like(b)
+            _L().axpy_dev_f32(_p(a), _p(k), None, _p(gb), a.numel(), _st())
+        return ga, gb, None
+
+
+def dot_all(a, b, scale=1.0):
+    return _DotAll.apply(a.contiguous(), b.contiguous(), float(scale))
+
+
 class _Gram(torch.autograd.Function):
     """G[n] = X[n]^T X[n] / (C*P), X [N,P,C]   (external_function.py:180-185)."""
 

@@ -1,8 +1,8 @@
-"""Host-side mirror of modules/psp/criteria/__init__.py (pSpLoss.__call__, criteria/__init__.py:44-99) for the terms that
-can run offline: masked / plain L2, the reference-side L2, the W-norm term, and the VGG style / contextual terms (which the
-reference computes for logging only -- they are never added to ``loss``, criteria/__init__.py:74-76,88-90).  LPIPS and the
-ArcFace identity loss need weights that are only obtainable by network download: a non-zero
-lambda for them raises."""
+"""Host-side mirror of modules/psp/criteria/__init__.py (pSpLoss.__call__, criteria/__init__.py:44-99): ArcFace identity loss,
+masked / plain L2, LPIPS-alex (masked), the reference-side LPIPS / L2, the W-norm term, and the VGG style / contextual terms (which the
+reference computes for logging only -- they are never added to ``loss``, criteria/__init__.py:74-76,88-90).  The LPIPS / ArcFace
+WEIGHTS are download-only: they are read from local files when present and stay randomly
+initialised otherwise (weight parity unpinned)."""
 from __future__ import annotations
 
 import torch
@@ -10,6 +10,8 @@ from torch import nn
 
 from .... import functional as FF
 from ...loss import VGGLoss
+from . import id_loss
+from .lpips.lpips import LPIPS
 
 
 class WNormLoss(nn.Module):
@@ -32,8 +34,10 @@ class pSpLoss(nn.Module):
         self.id_lambda, self.lpips_lambda, self.l2_lambda, self.style_lambda = args.id_lambda, args.lpips_lambda, args.l2_lambda, args.style_lambda
         self.lpips_lambda_ref, self.l2_lambda_ref, self.cx_lambda = args.lpips_lambda_ref, args.l2_lambda_ref, args.cx_lambda
         self.w_norm_lambda = args.w_norm_lambda
-        if self.lpips_lambda > 0 or self.lpips_lambda_ref > 0 or self.id_lambda > 0:
-            raise NotImplementedError("LPIPS / ID losses need downloaded weights (out of scope offline): set their lambdas to 0")
+        if self.lpips_lambda > 0:  # the reference builds it on lpips_lambda alone and uses it for lpips_lambda_ref too (:29-30,82-85)
+            self.lpips_loss = LPIPS(net_type="alex").eval()
+        if self.id_lambda > 0:
+            self.id_loss = id_loss.IDLoss().eval()
         if self.w_norm_lambda > 0:
             self.w_norm_loss = WNormLoss(start_from_latent_avg=args.start_from_latent_avg)
         if self.style_lambda > 0:
@@ -43,6 +47,11 @@ class pSpLoss(nn.Module):
         loss_dict, loss, id_logs = {}, 0.0, None
         m = mask.contiguous() if mask is not None else None  # [N,H,W]
         yh = FF.to_nhwc(y_hat)
+        if self.id_lambda > 0:
+            loss_id, sim_improvement, id_logs = self.id_loss(y_hat, y, x)
+            loss_dict["loss_id"] = float(loss_id.detach())
+            loss_dict["id_improve"] = float(sim_improvement)
+            loss = loss_id * self.id_lambda
         if self.l2_lambda > 0:
             if m is not None:
                 loss_l2 = FF.mse_loss(FF.mask_mul(yh, m, True), FF.mask_mul(FF.to_nhwc(y), m, True))
@@ -50,12 +59,23 @@ class pSpLoss(nn.Module):
                 loss_l2 = FF.mse_loss(yh, FF.to_nhwc(y))
             loss_dict["loss_l2"] = float(loss_l2.detach())
             loss = loss + loss_l2 * self.l2_lambda
+        if self.lpips_lambda > 0:
+            if m is not None:
+                loss_lpips = self.lpips_loss(FF.to_nchw(FF.mask_mul(yh, m, True)), FF.to_nchw(FF.mask_mul(FF.to_nhwc(y), m, True)))
+            else:
+                loss_lpips = self.lpips_loss(y_hat, y)
+            loss_dict["loss_lpips"] = float(loss_lpips.detach())
+            loss = loss + loss_lpips * self.lpips_lambda
         if self.style_lambda > 0 and m is not None:
             with torch.no_grad():  # logged only in the reference (criteria/__init__.py:74-76)
                 loss_dict["loss_style"] = float(self.vgg_loss(FF.to_nchw(FF.mask_mul(yh, m, True)), x, lossType="style") * self.style_lambda)
         if ref is not None:
             rf = FF.mask_mul(FF.to_nhwc(ref), m, False)
             yhm = FF.mask_mul(yh, m, False)
+            if self.lpips_lambda_ref > 0:
+                loss_lpips_ref = self.lpips_loss(FF.to_nchw(yhm), FF.to_nchw(rf))
+                loss_dict["loss_lpips_ref"] = float(loss_lpips_ref.detach())
+                loss = loss + loss_lpips_ref * self.lpips_lambda_ref
             if self.l2_lambda_ref > 0:
                 loss_l2_ref = FF.mse_loss(yhm, rf)
                 loss_dict["loss_l2_ref"] = float(loss_l2_ref.detach())

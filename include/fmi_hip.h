@@ -278,6 +278,15 @@ int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const float* o_r
 /* k x k mean pooling, stride k (nn.AvgPool2d(2,2) base_function.py:233; AdaptiveAvgPool2d 1024->256 model.py:79) */
 int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
 int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream);
+/* y[r][:] = x[r][:] / (||x[r]|| + eps), inv_norm[r] = 1 / (||x[r]|| + eps): LPIPS' normalize_activation over the channels of a
+ * pixel (criteria/lpips/utils.py:6-8, eps 1e-10) and ArcFace's l2_norm of an embedding (encoders/helpers.py:15-18, eps 0) */
+int fmi_l2norm_rows_f32(const float* x, float* y, float* inv_norm, int64_t rows, int C, float eps, void* stream);
+int fmi_l2norm_rows_bwd_f32(const float* g, const float* y, const float* inv_norm, float* gx, int64_t rows, int C, float eps, void* stream);
+/* out[0] += scale * sum_p sum_c w[c] (fx[p][c] - fy[p][c])^2: one layer of LPIPS.forward (criteria/lpips/lpips.py:33-36: squared
+ * difference, 1x1 lin convolution, spatial mean, batch sum) in one pass; caller zeroes out.  Backward: gfx / gfy may be NULL */
+int fmi_lpips_layer_f32(const float* fx, const float* fy, const float* w, float* out, int64_t pixels, int C, float scale, void* stream);
+int fmi_lpips_layer_bwd_f32(const float* fx, const float* fy, const float* w, const float* gout, float* gfx, float* gfy, int64_t pixels,
+                            int C, float scale, void* stream);
 /* dst[r][dst_c0 + j] = src[r][src_c0 + j] for j < c: channel slice / concatenation of NHWC maps (model.py:106 return_zq;
  * unet_parts.py:70 and example_guided_att.py:37 torch.cat) */
 int fmi_copy_channels_f32(const float* src, float* dst, int64_t rows, int src_stride, int src_c0, int dst_stride, int dst_c0, int c,

@@ -846,3 +846,93 @@ def dataset_fixture():
 
 if __name__ == "__main__":
     dataset_fixture()
+
+
+def psp_criteria_fixture():
+    """LPIPS(alex) (criteria/lpips/lpips.py:30-36), IDLoss (criteria/id_loss.py:22-50) and pSpLoss.__call__ with every lambda on
+    (criteria/__init__.py:44-99) from the reference's own code.  torchvision's AlexNet and the downloaded weights are absent: the
+    trunk is the standard ``alexnet().features`` stack from a stand-in ``torchvision.models.alexnet``, all parameters come from
+    oracle/seeded.py (seeds stored), and the objects are assembled without the constructors' ``.to("cuda")`` / ``torch.load`` /
+    URL fetch -- their ``forward`` / ``__call__`` code is the reference's, unmodified."""
+    import torch.nn as nn
+
+    sg = _import_stylegan2()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from seeded import grad_digest, seeded_fill_
+
+    def alexnet(pretrained=False, **_):
+        m = nn.Module()
+        m.features = nn.Sequential(
+            nn.Conv2d(3, 64, kernel_size=11, stride=4, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.Conv2d(64, 192, kernel_size=5, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2),
+            nn.Conv2d(192, 384, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(384, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, kernel_size=3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2))
+        return m
+
+    sys.modules["torchvision"].models.alexnet = alexnet
+    sys.modules["torchvision.models"].alexnet = alexnet
+    from modules.psp import criteria as CR
+    from modules.psp.criteria import id_loss as IDL, w_norm
+    from modules.psp.criteria.lpips import lpips as LP, networks as LN
+    from modules.psp.encoders.model_irse import Backbone
+
+    lp = LP.LPIPS.__new__(LP.LPIPS)
+    nn.Module.__init__(lp)
+    lp.net = LN.AlexNet()
+    lp.lin = LN.LinLayers(lp.net.n_channels_list)
+    seeded_fill_(lp, 501)
+    lp.eval()
+    idl = IDL.IDLoss.__new__(IDL.IDLoss)
+    nn.Module.__init__(idl)
+    idl.facenet = Backbone(input_size=112, num_layers=50, drop_ratio=0.6, mode="ir_se")
+    seeded_fill_(idl.facenet, 502)
+    idl.face_pool = torch.nn.AdaptiveAvgPool2d((112, 112))
+    idl.facenet.eval()
+
+    from seeded import criteria_inputs
+
+    x, y, rf, yh, mask = criteria_inputs(71)
+    yh.requires_grad_(True)
+    g = torch.Generator().manual_seed(72)
+    # random weights map every face to almost the same embedding (cosine ~ 1 - 1e-4): centre the BatchNorm1d output on these inputs
+    # so that the identity loss discriminates; the adjusted bias travels in the fixture
+    with torch.no_grad():
+        def pre(img):
+            f = idl.face_pool(img[:, :, 35:223, 32:220])
+            return idl.facenet.output_layer(idl.facenet.body(idl.facenet.input_layer(f)))
+        zbar = torch.cat([pre(x), pre(y), pre(yh)]).mean(0)
+        idl.facenet.output_layer[4].bias -= zbar
+    fx = dict(seeds=dict(lpips=501, facenet=502, inputs=71), facenet_bn1d_bias=idl.facenet.output_layer[4].bias.detach().clone())
+    v = lp(yh, y)
+    v.backward()
+    fx["lpips"] = dict(out=v.detach(), gy_hat=grad_digest(yh.grad, 16384))
+    yh.grad = None
+    l, imp, logs = idl(yh, y, x)
+    l.backward()
+    fx["id"] = dict(loss=l.detach(), improve=torch.tensor(float(imp)), logs=torch.tensor([[d["diff_target"], d["diff_input"], d["diff_views"]] for d in logs]),
+                    gy_hat=grad_digest(yh.grad, 16384), feats_y=idl.extract_feats(y).detach())
+    yh.grad = None
+    args = types.SimpleNamespace(id_lambda=0.1, lpips_lambda=0.8, l2_lambda=2.0, style_lambda=0.0, lpips_lambda_ref=0.4, l2_lambda_ref=0.7,
+                                 cx_lambda=0.0, w_norm_lambda=0.005, start_from_latent_avg=True)
+    crit = CR.pSpLoss.__new__(CR.pSpLoss)
+    nn.Module.__init__(crit)
+    for k, val in vars(args).items():
+        if k.endswith("lambda") or k.endswith("lambda_ref"):
+            setattr(crit, k, val)
+    crit.mse_loss = nn.MSELoss().eval()
+    crit.lpips_loss, crit.id_loss = lp, idl
+    crit.w_norm_loss = w_norm.WNormLoss(start_from_latent_avg=True)
+    lat = torch.randn(2, 14, 512, generator=g, requires_grad=True)
+    lavg = torch.randn(14, 512, generator=g)
+    loss, ld, id_logs = crit(x, y, yh, lat, latent_avg=lavg, ref=rf, mask=mask)
+    loss.backward()
+    fx["psp_loss_full"] = dict(args={k: float(val) if not isinstance(val, bool) else val for k, val in vars(args).items()}, latent=lat.detach(), latent_avg=lavg,
+                               loss=loss.detach(), loss_dict={k: torch.tensor(val) for k, val in ld.items()}, gy_hat=grad_digest(yh.grad, 16384), glatent=lat.grad.clone())
+    torch.save(fx, os.path.join(OUT, "psp_criteria.pt"))
+    print("psp_criteria: lpips %.5f id %.5f loss %.5f" % (float(v), float(l), float(loss)), {k: round(val, 5) for k, val in ld.items()},
+          "%.2f MB" % (os.path.getsize(os.path.join(OUT, "psp_criteria.pt")) / 1e6))
+
+
+if __name__ == "__main__":
+    psp_criteria_fixture()

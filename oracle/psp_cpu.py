@@ -155,3 +155,70 @@ def psp_loss(y, y_hat, latent, latent_avg=None, ref=None, mask=None, l2_lambda=1
     if w_norm_lambda > 0 and latent_avg is not None:
         loss = loss + w_norm_lambda * w_norm(latent, latent_avg if start_from_latent_avg else None)
     return loss
+
+
+# ---- LPIPS(alex) and the ArcFace identity loss (criteria/lpips/*, criteria/id_loss.py, encoders/model_irse.py) -------------
+ALEX_LAYERS = (("conv", 0, 4, 2), ("relu",), ("pool",), ("conv", 3, 1, 2), ("relu",), ("pool",), ("conv", 6, 1, 1), ("relu",),
+               ("conv", 8, 1, 1), ("relu",), ("conv", 10, 1, 1), ("relu",), ("pool",))
+ALEX_TARGETS = (2, 5, 8, 10, 12)
+
+
+def lpips_alex(P: Params, prefix: str, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """LPIPS.forward (lpips.py:30-36) with BaseNet.forward (networks.py:49-62) and normalize_activation (utils.py:6-8)"""
+    def feats(t):
+        t = (t - P[prefix + "net.mean"]) / P[prefix + "net.std"]
+        out = []
+        for i, op in enumerate(ALEX_LAYERS, 1):
+            if op[0] == "conv":
+                t = F.conv2d(t, P[f"{prefix}net.layers.{op[1]}.weight"], P[f"{prefix}net.layers.{op[1]}.bias"], stride=op[2], padding=op[3])
+            elif op[0] == "relu":
+                t = F.relu(t)
+            else:
+                t = F.max_pool2d(t, 3, 2)
+            if i in ALEX_TARGETS:
+                out.append(t / (torch.sqrt(torch.sum(t ** 2, dim=1, keepdim=True)) + 1e-10))
+        return out
+
+    res = [F.conv2d((a - b) ** 2, P[f"{prefix}lin.{j}.1.weight"]).mean((2, 3), True) for j, (a, b) in enumerate(zip(feats(x), feats(y)))]
+    return torch.sum(torch.cat(res, 0)) / x.shape[0]
+
+
+def arcface_backbone(P: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """Backbone(112, 50, 'ir_se').forward in eval mode (model_irse.py:39-43) + l2_norm (helpers.py:15-18)"""
+    x = F.conv2d(x, P[prefix + "input_layer.0.weight"], padding=1)
+    x = prelu(P, prefix + "input_layer.2", batch_norm(P, prefix + "input_layer.1", x, False))
+    for i, s in enumerate(body_strides(50)):
+        x = bottleneck(P, f"{prefix}body.{i}", x, s, False)
+    x = batch_norm(P, prefix + "output_layer.0", x, False).flatten(1)
+    x = F.linear(x, P[prefix + "output_layer.3.weight"], P[prefix + "output_layer.3.bias"])
+    x = F.batch_norm(x, P[prefix + "output_layer.4.running_mean"], P[prefix + "output_layer.4.running_var"], P[prefix + "output_layer.4.weight"],
+                     P[prefix + "output_layer.4.bias"], False, 0.1, 1e-5)
+    return x / torch.norm(x, 2, 1, True)
+
+
+def id_loss(P: Params, prefix: str, y_hat, y, x):
+    """IDLoss.forward (id_loss.py:28-50): returns (loss, sim_improvement, [diff_target, diff_input, diff_views] per sample)"""
+    ext = lambda t: arcface_backbone(P, prefix + "facenet.", F.adaptive_avg_pool2d(t[:, :, 35:223, 32:220], (112, 112)))
+    xf, yf, hf = ext(x), ext(y).detach(), ext(y_hat)
+    dt, di, dv = (hf * yf).sum(1), (hf * xf).sum(1), (yf * xf).sum(1)
+    return (1 - dt).mean(), float((dt.detach() - dv.detach()).mean()), torch.stack([dt, di, dv], 1).detach()
+
+
+def psp_loss_full(P: Params, x, y, y_hat, latent, latent_avg, ref, mask, a):
+    """pSpLoss.__call__ (criteria/__init__.py:44-99) with every term; ``a`` = the lambdas.  NOTE the reference ASSIGNS the identity
+    term (``loss = loss_id * id_lambda``, :56) and adds the rest; style / contextual are logged only"""
+    m = mask.unsqueeze(1)
+    loss = 0.0
+    if a["id_lambda"] > 0:
+        loss = id_loss(P, "id_loss.", y_hat, y, x)[0] * a["id_lambda"]
+    if a["l2_lambda"] > 0:
+        loss = loss + F.mse_loss(y_hat * (1 - m), y * (1 - m)) * a["l2_lambda"]
+    if a["lpips_lambda"] > 0:
+        loss = loss + lpips_alex(P, "lpips_loss.", y_hat * (1 - m), y * (1 - m)) * a["lpips_lambda"]
+    if a["lpips_lambda_ref"] > 0:
+        loss = loss + lpips_alex(P, "lpips_loss.", y_hat * m, ref * m) * a["lpips_lambda_ref"]
+    if a["l2_lambda_ref"] > 0:
+        loss = loss + F.mse_loss(y_hat * m, ref * m) * a["l2_lambda_ref"]
+    if a["w_norm_lambda"] > 0:
+        loss = loss + w_norm(latent, latent_avg) * a["w_norm_lambda"]
+    return loss

@@ -46,7 +46,7 @@ def _rule(key: str, v: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
 
 
 def seeded_fill_(module: torch.nn.Module, seed: int, prefix: str = "") -> None:
-    """in-place; FIR kernels (``*.kernel`` buffers) and integer buffers keep their values.  ``prefix`` lets a sub-module be
+    """in-place; FIR kernels (``*.kernel`` buffers), LPIPS' ``mean`` / ``std`` constants and integer buffers keep their values.  ``prefix`` lets a sub-module be
     filled exactly as it would be as part of the parent (keys are sorted WITH the prefix applied)."""
     g = torch.Generator().manual_seed(seed)
     sd = module.state_dict()
@@ -54,7 +54,7 @@ def seeded_fill_(module: torch.nn.Module, seed: int, prefix: str = "") -> None:
     with torch.no_grad():
         for k in sorted(sd, key=lambda k: prefix + k):
             v = sd[k]
-            if not v.is_floating_point() or k.endswith(".kernel") or v.data_ptr() in seen:
+            if not v.is_floating_point() or k.endswith(".kernel") or k.rsplit(".", 1)[-1] in ("mean", "std") or v.data_ptr() in seen:
                 continue
             seen.add(v.data_ptr())
             r = torch.randn(v.shape, generator=g, dtype=torch.float32)
@@ -123,3 +123,16 @@ def as_digest(t: torch.Tensor) -> dict:
     """a fully stored tensor in digest form (every entry sampled), so that check_adjudicated takes it"""
     f = t.detach().reshape(-1).float()
     return dict(sum=f.double().sum().float(), abs_sum=f.abs().double().sum().float(), max=f.abs().max(), sample=f, step=torch.tensor(1))
+
+
+def criteria_inputs(seed: int):
+    """x, y, ref, y_hat in [-1, 1] ([2, 3, 256, 256]) and a rectangular mask [2, 256, 256]: the inputs of the pSp criteria fixture"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    rf = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    yh = (y + 0.3 * torch.randn(2, 3, 256, 256, generator=g)).clamp(-1, 1)
+    mask = torch.zeros(2, 256, 256)
+    mask[0, 120:230, 60:200] = 1
+    mask[1, 100:240, 40:180] = 1
+    return x, y, rf, yh, mask

@@ -192,3 +192,36 @@ def test_psp_forward_against_oracle(dev):
         got, codes = net(x.to(dev), ref=ref.to(dev), src_mask=mask.to(dev), randomize_noise=False, return_latents=True)
     _close(codes, codes_w, 1e-3, "codes")
     _close(got, want, 1e-3, "image")
+
+
+def test_lpips_id_and_full_psp_loss_against_reference(dev, golden):
+    """LPIPS(alex), IDLoss (ArcFace IR-SE50, eval) and pSpLoss.__call__ with every lambda on -- scripts/train_psp.sh's loss -- against
+    the reference's own forward code on seeded parameters (tests/golden/psp_criteria.pt): values 1e-3, gradients w.r.t. y_hat and the
+    latent codes"""
+    from oracle.seeded import check_digest, criteria_inputs  # checker
+    from test_oracle_criteria import criterion
+
+    fx = golden("psp_criteria.pt")
+    crit = criterion(fx).to(dev)
+    x, y, rf, yh, mask = (t.to(dev) for t in criteria_inputs(fx["seeds"]["inputs"]))
+    yh.requires_grad_(True)
+    v = crit.lpips_loss(yh, y)
+    assert abs(float(v) / float(fx["lpips"]["out"]) - 1) <= 1e-3
+    v.backward()
+    check_digest(yh.grad, fx["lpips"]["gy_hat"], 2e-3, "d lpips / d y_hat")
+    yh.grad = None
+    l, imp, logs = crit.id_loss(yh, y, x)
+    assert abs(float(l) / float(fx["id"]["loss"]) - 1) <= 1e-3 and abs(imp - float(fx["id"]["improve"])) <= 1e-3
+    torch.testing.assert_close(torch.tensor([[d["diff_target"], d["diff_input"], d["diff_views"]] for d in logs]), fx["id"]["logs"], rtol=1e-3, atol=1e-3)
+    l.backward()
+    check_digest(yh.grad, fx["id"]["gy_hat"], 5e-3, "d id / d y_hat")
+    yh.grad = None
+    f = fx["psp_loss_full"]
+    lat = f["latent"].to(dev).requires_grad_(True)
+    loss, ld, id_logs = crit(x, y, yh, lat, latent_avg=f["latent_avg"].to(dev), ref=rf, mask=mask)
+    assert abs(float(loss) / float(f["loss"]) - 1) <= 1e-3
+    for k, want in f["loss_dict"].items():
+        assert abs(ld[k] - float(want)) <= 1e-3 * abs(float(want)) + 1e-6, (k, ld[k], float(want))
+    loss.backward()
+    check_digest(yh.grad, f["gy_hat"], 5e-3, "d loss / d y_hat")
+    torch.testing.assert_close(lat.grad.cpu(), f["glatent"], rtol=1e-3, atol=1e-8)
