@@ -33,6 +33,10 @@ class AdamEntry(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64)]
 
 
+class RangerEntry(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("slow", vp), ("row_mean", vp), ("n", i64), ("cols", i64)]
+
+
 PD = C.POINTER(ConvDesc)
 
 # name -> argtypes (return type is always int status unless noted)
@@ -109,6 +113,7 @@ SIGNATURES = {
     "fmi_cx_loss_f32": [vp, vp, vp, i32, i32, f32, vp],
     "fmi_cx_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
     "fmi_adam_step_f32": [vp, i32, i64, f32, f32, f32, f32, f32, i32, vp],
+    "fmi_ranger_step_f32": [vp, i32, f32, f32, f32, f32, f32, f32, i32, f32, i32, vp],
     "fmi_upfirdn2d_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fmi_upfirdn2d_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fmi_fused_bias_act_f32": [vp, vp, vp, vp, i64, i32, i32, i32, i32, f32, f32, vp],

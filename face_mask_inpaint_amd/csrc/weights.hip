@@ -296,3 +296,72 @@ extern "C" int fmi_adam_step_f32(const fmi_adam_entry* entries, int count, int64
   }
   return fmi_launch_status();
 }
+
+// ---- multi-tensor Ranger = RAdam + Lookahead + gradient centralisation (modules/psp/ranger.py:92-184) ----------------------
+// launch 1 (tensors of more than gc_dim dimensions): mean[r] of every gradient row; launch 2: the element-wise update in the
+// reference's order -- g -= mean[row]; v = v beta2 + (1 - beta2) g g; m = m beta1 + (1 - beta1) g; weight decay; p -= step_size lr
+// m / (sqrt(v) + eps) (rectified) or p -= step_size lr m; every k-th step slow += alpha (p - slow), p = slow
+struct RangerArgs { fmi_ranger_entry e[ENTRY_CHUNK]; };
+__global__ void __launch_bounds__(256) ranger_rowmean_kernel(const RangerArgs args) {
+  __shared__ double red[4];
+  const fmi_ranger_entry e = args.e[blockIdx.y];
+  if (!e.row_mean) return;
+  const int64_t rows = e.n / e.cols;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    double s = 0.0;
+    for (int64_t c = threadIdx.x; c < e.cols; c += 256) s += (double)e.g[r * e.cols + c];
+    s = block_sum_256_d(s, red);
+    if (threadIdx.x == 0) e.row_mean[r] = (float)(s / (double)e.cols);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) ranger_kernel(const RangerArgs args, float lr, float beta1, float beta2, float eps, float wd,
+                                                     float step_size, int rectified, float alpha, int lookahead) {
+  const fmi_ranger_entry e = args.e[blockIdx.y];
+  const int64_t base = (int64_t)blockIdx.x * ADAM_CHUNK;
+  if (base >= e.n) return;
+  for (int64_t i = base + threadIdx.x; i < base + ADAM_CHUNK && i < e.n; i += 256) {
+    float g = e.g[i];
+    if (e.row_mean) g -= e.row_mean[i / e.cols];
+    const float v = e.v[i] * beta2 + (1.f - beta2) * g * g;
+    const float m = e.m[i] * beta1 + (1.f - beta1) * g;
+    e.v[i] = v;
+    e.m[i] = m;
+    float p = e.p[i];
+    if (wd != 0.f) p += -wd * lr * p;
+    if (rectified)
+      p += -step_size * lr * (m / (sqrtf(v) + eps));
+    else
+      p += -step_size * lr * m;
+    if (lookahead) {
+      const float s = e.slow[i] + alpha * (p - e.slow[i]);
+      e.slow[i] = s;
+      p = s;
+    }
+    e.p[i] = p;
+  }
+}
+extern "C" int fmi_ranger_step_f32(const fmi_ranger_entry* entries, int count, float lr, float beta1, float beta2, float eps,
+                                   float weight_decay, float step_size, int rectified, float alpha, int lookahead, void* stream) {
+  if (!entries || count <= 0) return FMI_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < count; base += ENTRY_CHUNK) {
+    RangerArgs a;
+    const int n = count - base < ENTRY_CHUNK ? count - base : ENTRY_CHUNK;
+    int64_t mx = 0, max_rows = 0;
+    for (int i = 0; i < n; ++i) {
+      a.e[i] = entries[base + i];
+      const fmi_ranger_entry& e = a.e[i];
+      if (!e.p || !e.g || !e.m || !e.v || !e.slow || e.n <= 0 || e.cols <= 0 || e.n % e.cols) return FMI_ERR_BAD_ARG;
+      if (e.n > mx) mx = e.n;
+      if (e.row_mean && e.n / e.cols > max_rows) max_rows = e.n / e.cols;
+    }
+    if (max_rows > 0)
+      hipLaunchKernelGGL(ranger_rowmean_kernel, dim3((unsigned)(max_rows < 4096 ? max_rows : 4096), n), dim3(256), 0, st, a);
+    const int64_t gx = ceil_div64(mx, ADAM_CHUNK);
+    if (gx > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ranger_kernel, dim3((unsigned)gx, n), dim3(256), 0, st, a, lr, beta1, beta2, eps, weight_decay, step_size, rectified,
+                       alpha, lookahead);
+  }
+  return fmi_launch_status();
+}

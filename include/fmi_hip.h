@@ -378,6 +378,15 @@ typedef struct {
 } fmi_adam_entry;
 int fmi_adam_step_f32(const fmi_adam_entry* entries /* HOST array */, int count, int64_t max_n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, void* stream);
+/* multi-tensor Ranger step = RAdam + Lookahead + gradient centralisation (modules/psp/ranger.py:92-184, the --optimizer ranger of
+ * train_psp.py:290-293).  row_mean (scratch, rows floats) non-NULL = centralise: g -= mean of its row (tensors with more than one
+ * dimension, cols = numel / shape[0]); step_size / rectified from the host (the RAdam variance rectification depends on the step
+ * count only); lookahead != 0 on every k-th step: slow += alpha (p - slow), p = slow */
+typedef struct {
+  float* p; const float* g; float* m; float* v; float* slow; float* row_mean; int64_t n; int64_t cols;
+} fmi_ranger_entry;
+int fmi_ranger_step_f32(const fmi_ranger_entry* entries /* HOST array */, int count, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float step_size, int rectified, float alpha, int lookahead, void* stream);
 
 /* ------------------------------------------------------------------------
  * The reference's own native ops (modules/psp/stylegan2/op).

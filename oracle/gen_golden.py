@@ -936,3 +936,30 @@ def psp_criteria_fixture():
 
 if __name__ == "__main__":
     psp_criteria_fixture()
+
+
+def ranger_fixture():
+    """the reference's Ranger (modules/psp/ranger.py) for 13 steps on a conv weight, a linear weight, a bias and a scalar (crosses the
+    N_sma threshold at step 6 and two Lookahead syncs at steps 6 / 12); gradients stored, parameters after every step"""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from modules.psp.ranger import Ranger
+
+    g = torch.Generator().manual_seed(81)
+    shapes = [(6, 4, 3, 3), (5, 7), (9,), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    fx = dict(p0=[p.detach().clone() for p in ps], grads=[], params=[], cfg=dict(lr=1e-2, weight_decay=1e-3))
+    opt = Ranger(ps, lr=1e-2, weight_decay=1e-3)
+    for step in range(13):
+        gs = [torch.randn(s, generator=g) * (1 + 0.1 * step) for s in shapes]
+        for p, gr in zip(ps, gs):
+            p.grad = gr.clone()
+        opt.step()
+        fx["grads"].append(gs)
+        fx["params"].append([p.detach().clone() for p in ps])
+    torch.save(fx, os.path.join(OUT, "ranger.pt"))
+    print("ranger: 13 steps,", [tuple(s) for s in shapes])
+
+
+if __name__ == "__main__":
+    ranger_fixture()

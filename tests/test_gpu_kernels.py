@@ -617,3 +617,23 @@ def test_global_average_pool(dev, FF, n, h, c):
     gy = torch.randn(n, 1, 1, c, generator=g)
     y.backward(gy.to(dev))
     torch.testing.assert_close(xd.grad.cpu(), (gy / (h * h)).expand(n, h, h, c), rtol=1e-6, atol=1e-8)
+
+
+def test_ranger_against_reference(dev, golden):
+    """Ranger (RAdam + Lookahead + gradient centralisation, modules/psp/ranger.py) as one multi-tensor launch pair: 13 steps on the
+    gradients of tests/golden/ranger.pt against the parameters the reference's optimiser produced (crosses the rectification
+    threshold and two Lookahead syncs)"""
+    from face_mask_inpaint_amd.modules.psp.ranger import Ranger
+
+    fx = golden("ranger.pt")
+    ps = [torch.nn.Parameter(p.clone().to(dev)) for p in fx["p0"]]
+    opt = Ranger(ps, **fx["cfg"])
+    for step, (gs, want) in enumerate(zip(fx["grads"], fx["params"])):
+        for p, g in zip(ps, gs):
+            p.grad = g.clone().to(dev)
+        opt.step()
+        for i, (p, w) in enumerate(zip(ps, want)):
+            torch.testing.assert_close(p.detach().cpu(), w, rtol=2e-5, atol=2e-6, msg=lambda m, i=i, step=step: f"step {step} tensor {i}: {m}")
+    assert set(opt.state[ps[0]]) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"} and opt.state[ps[0]]["step"] == 13
+    with pytest.raises(ValueError):
+        Ranger(ps, alpha=1.5)
