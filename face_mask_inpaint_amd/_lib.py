@@ -18,7 +18,7 @@ i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 class ConvDesc(C.Structure):
     """fmi_conv_desc (include/fmi_hip.h)."""
 
-    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode")]
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode", "dil")]
 
 
 class WeightEntry(C.Structure):

@@ -14,8 +14,9 @@ static int check_desc(const fmi_conv_desc* d) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 ||
       d->pad < 0 || d->x_cstride < d->C || d->y_cstride < d->K)
     return FMI_ERR_BAD_ARG;
-  const int pe = d->pad;
-  if (d->OH != (d->H + 2 * pe - d->kh) / d->stride + 1 || d->OW != (d->W + 2 * pe - d->kw) / d->stride + 1)
+  const int pe = d->pad, dl = d->dil > 1 ? d->dil : 1;
+  if (d->dil < 0 || (dl > 1 && d->pad_mode)) return FMI_ERR_BAD_ARG;
+  if (d->OH != (d->H + 2 * pe - dl * (d->kh - 1) - 1) / d->stride + 1 || d->OW != (d->W + 2 * pe - dl * (d->kw - 1) - 1) / d->stride + 1)
     return FMI_ERR_BAD_ARG;
   if (d->OH <= 0 || d->OW <= 0) return FMI_ERR_BAD_ARG;
   if (d->pad_mode == 1 && (d->pad >= d->H || d->pad >= d->W)) return FMI_ERR_UNSUPPORTED;
@@ -29,7 +30,8 @@ static ConvGeom fwd_geom(const fmi_conv_desc* d, const float* x, int n_eff) {
   ConvGeom g{};
   g.N = n_eff; g.IH = d->H; g.IW = d->W; g.C = d->C; g.cstride = d->x_cstride;
   g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
-  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = 1; g.xstep = 1;
+  const int dl = d->dil > 1 ? d->dil : 1;  // dilation = the tap step of the gather (modules/drn.py)
+  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = dl; g.xstep = dl;
   g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
   g.pad_mode = d->pad_mode;
   g.vec = (d->C % 4 == 0) && (d->x_cstride % 4 == 0) && aligned16(x);
@@ -104,7 +106,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
 #ifndef FMI_HOST_EMU
   const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
   static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
-  const bool c3 = !c3_off && !(FMI_EXP & 32) && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0 &&
+  const bool c3 = !c3_off && !(FMI_EXP & 32) && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0 && d->dil <= 1 &&
                   conv3x3_eligible(x, wf, d->C, d->x_cstride, d->K, (int64_t)d->N * d->H * d->W);
   if (c3) {
     C3Args ca{x, wf, d->N, d->H, d->W, d->C, d->x_cstride, d->K, 0, make_fastdiv(d->W), make_fastdiv(d->H * d->W)};
@@ -151,6 +153,8 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
 #endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;
+  const int dl = d->dil > 1 ? d->dil : 1;
+  if (dl > 1 && s != 1) return FMI_ERR_UNSUPPORTED;  // adjoint of a dilated AND strided convolution: not needed by modules/drn.py
 #ifndef FMI_HOST_EMU
   // Strided adjoints of small feature maps (the stride-2 style heads of the pSp encoder: 512 -> 512 at 16^2 .. 2^2) are a few
   // output tiles per sub-pixel phase with up to 128 reduction tiles each -- 0.25 ms of pure load latency per call.  If any phase
@@ -182,7 +186,7 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
       g.nty = g.kh0 < d->kh ? (d->kh - g.kh0 + s - 1) / s : 0;
       g.ntx = g.kw0 < d->kw ? (d->kw - g.kw0 + s - 1) / s : 0;
       g.dy0 = (py + d->pad - g.kh0) / s; g.dx0 = (px + d->pad - g.kw0) / s;
-      g.ystep = -1; g.xstep = -1; g.khstep = s; g.kwstep = s; g.kw = d->kw;
+      g.ystep = -dl; g.xstep = -dl; g.khstep = s; g.kwstep = s; g.kw = d->kw;  // dl > 1 only with s == 1 (checked above)
       g.pad_mode = 0;
       g.vec = (d->K % 4 == 0) && (d->y_cstride % 4 == 0) && aligned16(dy);
       g.dGW = make_fastdiv(GW); g.dG = make_fastdiv(GH * GW); g.dC = make_fastdiv(g.C);
@@ -208,7 +212,7 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
       }
       const int ks = (s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1;
       static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
-      const bool c3 = !c3_off && !(FMI_EXP & 32) && s == 1 && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 &&
+      const bool c3 = !c3_off && !(FMI_EXP & 32) && s == 1 && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->dil <= 1 &&
                       conv3x3_eligible(dy, wt, d->K, d->y_cstride, d->C, (int64_t)d->N * d->H * d->W);
       if (c3) {  // adjoint of a 3x3 stride-1 pad-1 convolution = the same convolution of dy with flipped taps
         C3Args ca{dy, wt, d->N, d->OH, d->OW, d->K, d->y_cstride, d->C, 1, make_fastdiv(d->OW), make_fastdiv(d->OH * d->OW)};

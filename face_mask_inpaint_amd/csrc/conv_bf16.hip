@@ -394,6 +394,7 @@ static int check_desc_b(const fmi_conv_desc* d) {
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0 ||
       d->x_cstride < d->C || d->y_cstride < d->K)
     return FMI_ERR_BAD_ARG;
+  if (d->dil > 1) return FMI_ERR_UNSUPPORTED;  // dilated convolutions (modules/drn.py) exist in the fp32 family only
   if (d->OH != (d->H + 2 * d->pad - d->kh) / d->stride + 1 || d->OW != (d->W + 2 * d->pad - d->kw) / d->stride + 1) return FMI_ERR_BAD_ARG;
   if (d->OH <= 0 || d->OW <= 0) return FMI_ERR_BAD_ARG;
   if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;

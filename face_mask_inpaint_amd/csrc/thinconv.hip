@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256) thin_dgrad_mfma_kernel(ThinArgs a, float*
 
 bool thin_shape_ok(const fmi_conv_desc* d) {
   const int cg = d->C / 4;
-  return (int64_t)d->N * d->H * d->W < (1ll << 31) && d->K >= 1 && d->K <= 4 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->C % 4 == 0 && cg >= 1 &&
+  return d->dil <= 1 && (int64_t)d->N * d->H * d->W < (1ll << 31) && d->K >= 1 && d->K <= 4 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->C % 4 == 0 && cg >= 1 &&
          cg <= 16 && (cg & (cg - 1)) == 0 && d->x_cstride % 4 == 0 && d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W;
 }
 
@@ -681,7 +681,7 @@ extern "C" int fmi_conv2d_thin_lrelu_dgrad_f32(const fmi_conv_desc* d, const flo
 extern "C" int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, float* dx, void* stream) {
   if (!d || !dy || !wt || !dx) return FMI_ERR_BAD_ARG;
   const int cg = d->K / 4;
-  if (d->C < 1 || d->C > 4 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->K % 4 != 0 || cg < 1 ||
+  if (d->dil > 1 || d->C < 1 || d->C > 4 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != 0 || d->K % 4 != 0 || cg < 1 ||
       cg > 16 || (cg & (cg - 1)) != 0 || d->y_cstride % 4 != 0 || d->H < 3 || d->W < 3 || d->OH != d->H || d->OW != d->W ||
       ((uintptr_t)dy & 15) || (int64_t)d->N * d->H * d->W >= (1ll << 31))
     return FMI_ERR_UNSUPPORTED;

@@ -136,10 +136,10 @@ def eltwise(op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, p0: floa
     return y
 
 
-def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None) -> Tuple[ConvDesc, int, int]:
-    oh = (h + 2 * pad - kh) // stride + 1
-    ow = (w + 2 * pad - kw) // stride + 1
-    return ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode), oh, ow
+def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1) -> Tuple[ConvDesc, int, int]:
+    oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    return ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode, dil), oh, ow
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -244,7 +244,7 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, W) + bias + residual); x [N,H,W,C], wf [taps][C][K]."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False):
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False, dil=1):
         """in_act: None, ("apply", slope): the convolution reads lrelu(x, slope) (computed here, and only IT is kept for the backward),
         ("mask", slope): x already is the output of such an activation; either way the input gradient is multiplied by act'(x) in the
         adjoint's epilogue.  skip_act_bwd: this convolution's own fused activation (act) is differentiated by its single consumer (a
@@ -255,12 +255,13 @@ class _Conv2d(torch.autograd.Function):
             x = eltwise(EW_LRELU, x, None, in_act[1])
         n, h, w, c = x.shape
         k = wf.shape[2]
-        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
-        with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * n * oh * ow * k * c * kh * kw):
+        with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}" + (f"d{dil}" if dil > 1 else ""), 2.0 * n * oh * ow * k * c * kh * kw):
             lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
         ctx.save_for_backward(x, wf, y if (act and not skip_act_bwd) else None)
         ctx.wt, ctx.cfg, ctx.has = wt, (kh, kw, stride, pad, pad_mode, act), (bias is not None, residual is not None)
+        ctx.dil = dil
         ctx.in_slope = None if in_act is None else float(in_act[1])
         ctx.skip_act_bwd = bool(skip_act_bwd)
         return y
@@ -277,8 +278,9 @@ class _Conv2d(torch.autograd.Function):
         k = wf.shape[2]
         gx = gwf = gb = gres = None
         masked = False
+        dil = ctx.dil
         if ctx.needs_input_grad[0]:
-            d0, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+            d0, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
             if pad_mode == 1 and lib.conv2d_thin_supported(C.byref(d0)):  # thin output: adjoint and fold in one pass
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
@@ -292,7 +294,7 @@ class _Conv2d(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
-                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad)
+                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     if ctx.in_slope is not None:  # act'(x) folded into the adjoint's epilogue
@@ -303,7 +305,7 @@ class _Conv2d(torch.autograd.Function):
             if ctx.in_slope is not None and not masked:
                 gx = eltwise(EW_LRELU_BWD, gx, x, ctx.in_slope)
         if ctx.needs_input_grad[1]:
-            d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode)
+            d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
             gwf = _zeros_like(wf)
             want_gb = ctx.has[0] and ctx.needs_input_grad[2]
             fuse = want_gb and (kh * kw * c) % 4 == 0
@@ -316,7 +318,7 @@ class _Conv2d(torch.autograd.Function):
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
-        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None
 
 
 class _ThinConvLReLU(torch.autograd.Function):
@@ -375,12 +377,12 @@ def lrelu_conv2d(x, pw: PackedWeight, bias=None, slope=0.1, pad=1, pad_mode=0, a
     return conv2d(leaky_relu(x, slope), pw, bias, None, 1, pad, pad_mode, act)
 
 
-def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, in_act=None, skip_act_bwd=False):
+def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, in_act=None, skip_act_bwd=False, dilation=1):
     if x.dtype == BF16:
-        if bias is not None or residual is not None or pad_mode or act or in_act is not None:
-            raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding epilogue")
+        if bias is not None or residual is not None or pad_mode or act or in_act is not None or dilation != 1:
+            raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding / dilation form")
         return _Conv2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad)
-    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd)
+    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd, int(dilation))
 
 
 # ---- bf16 activations (StyleGAN2 decoder of configs C3 / C5): fp32 master weights, bf16 copies packed per call ----

@@ -20,10 +20,18 @@ class ReferenceFill(nn.Module):
         super().__init__()
         self.mask_detector = mask_detector
         self.encoder_type = encoder_params.pop("type")
-        if self.encoder_type != "pluralistic":
-            raise NotImplementedError("encoder type 'drn' (modules/drn.py) is not built: BASELINE configs use 'pluralistic'")
-        self.src_encoder = network.define_e(**encoder_params, encoder_type="src")
-        self.ref_encoder = network.define_e(**encoder_params, encoder_type="ref")
+        if self.encoder_type == "drn":  # model.py:47-59
+            from .drn import drn_c_42
+
+            self.src_encoder = drn_c_42(pretrained=False, out_map=True)
+            self.src_encoder.fc = torch.nn.Conv2d(self.src_encoder.out_dim, encoder_params["img_f"], kernel_size=1, stride=1, padding=0, bias=True)
+            self.ref_encoder = drn_c_42(pretrained=False, out_map=True)
+            self.ref_encoder.fc = torch.nn.Conv2d(self.ref_encoder.out_dim, encoder_params["img_f"], kernel_size=1, stride=1, padding=0, bias=True)
+        elif self.encoder_type == "pluralistic":
+            self.src_encoder = network.define_e(**encoder_params, encoder_type="src")
+            self.ref_encoder = network.define_e(**encoder_params, encoder_type="ref")
+        else:
+            raise NotImplementedError
         self.decoder = network.define_g(**decoder_params)
         self.use_att = use_att
         if use_att:
@@ -44,20 +52,25 @@ class ReferenceFill(nn.Module):
             # (F.interpolate of a 5-D bool tensor); the working call sites pass argmax masks (PICNet_inference.py:100-101)
             src_mask = self.mask_detector.predict_mask(src_image)
         skip = ()
-        if no_prior:  # the decoder's latent blocks do not run without z (network.py:253-260)
+        skip_z = no_prior or self.encoder_type == "drn"  # model.py:103-104: a DRN encoder has no latent distribution
+        if skip_z:  # the decoder's latent blocks do not run without z (network.py:253-260)
             skip = tuple(getattr(self.decoder, n) for n in ["generator"] + ["generator%d" % i for i in range(self.decoder.L)])
         with weight_scope(self, skip):
             src = FF.to_nhwc(src_image)
             ref = FF.to_nhwc(ref_image)
-            o_src, src_feat = self.src_encoder.nhwc_raw(src)
-            o_ref, ref_feat = self.ref_encoder.nhwc_raw(ref)
+            if self.encoder_type == "drn":
+                (src_feat, _), (ref_feat, _) = self.src_encoder.nhwc(src), self.ref_encoder.nhwc(ref)
+                o_src = o_ref = None
+            else:
+                o_src, src_feat = self.src_encoder.nhwc_raw(src)
+                o_ref, ref_feat = self.ref_encoder.nhwc_raw(ref)
             n, fh, fw, _ = src_feat.shape
             m = FF.resize_bilinear(src_mask.contiguous().unsqueeze(-1), fh, fw).view(n, fh, fw)
             if self.use_att:
                 enc = self.attention.nhwc(m, src_feat, ref_feat)
             else:  # (1 - m) * src + m * ref  (model.py:100-101)
                 enc = FF.add(FF.mask_mul(src_feat, m, True), FF.mask_mul(ref_feat, m, False))
-            if no_prior:
+            if skip_z:
                 img = self.decoder.nhwc(enc, None)
             else:
                 z_nc = o_src.shape[-1] // 2

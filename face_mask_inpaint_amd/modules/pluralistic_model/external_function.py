@@ -65,10 +65,10 @@ def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0
                 raise NotImplementedError("ConvTranspose2d with a masked input gradient")
             x_nhwc = FF.leaky_relu(x_nhwc, in_act[1])
         return FF.conv_transpose2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], conv.padding[0], conv.output_padding[0])
-    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1 or conv.dilation != (1, 1):
+    if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1 or conv.dilation[0] != conv.dilation[1]:
         raise NotImplementedError("Conv2d geometry outside the hot path")
     p = conv.padding[0] if pad is None else pad
-    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act, in_act, skip_act_bwd)
+    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act, in_act, skip_act_bwd, conv.dilation[0])
 
 
 class GANLoss(nn.Module):

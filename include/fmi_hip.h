@@ -75,6 +75,7 @@ typedef struct {
   int y_cstride;     /* floats between consecutive pixels of y (>= K) */
   int kh, kw, stride, pad;
   int pad_mode;      /* 0 = zeros, 1 = reflect (nn.ReflectionPad2d, base_function.py:390) */
+  int dil;           /* dilation (modules/drn.py: 2 / 4 in the dilated stages); 0 or 1 = none.  fp32 family only, stride 1 for the adjoint */
 } fmi_conv_desc;
 
 /* y = conv(x, wf) + bias[k] + residual ; bias/residual may be NULL.

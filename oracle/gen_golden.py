@@ -963,3 +963,51 @@ def ranger_fixture():
 
 if __name__ == "__main__":
     ranger_fixture()
+
+
+def drn_fixture():
+    """DRN-C-42 (modules/drn.py, 31 M parameters: seeded) in training mode, forward + backward on a 2 x 3 x 64 x 48 input with
+    out_map / out_middle, and ReferenceFill(encoder type 'drn') forward (model.py:47-59,88-90,103-104) with a tiny decoder"""
+    ref_model, ref_loss, ref_network = import_reference()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from seeded import grad_digest, seeded_fill_, seeded_tensor
+    from modules.drn import drn_c_42, drn_d_22
+
+    fx = {}
+    net = drn_c_42(pretrained=False, out_map=True, out_middle=True, num_classes=24)
+    seeded_fill_(net, 601)
+    net.train()
+    x = seeded_tensor((2, 3, 64, 48), 602).requires_grad_(True)
+    out, mids = net(x)
+    (out * seeded_tensor(out.shape, 603)).sum().backward()
+    sd = net.state_dict()
+    fx["drn_c_42"] = dict(seed=601, x_seed=602, cot_seed=603, out=out.detach().clone(), mids=[grad_digest(m, 4096) for m in mids], gx=x.grad.clone(),
+                          gparams={n: grad_digest(p.grad, 256) for n, p in net.named_parameters() if p.grad is not None},
+                          stats_after={k: sd[k].clone() for k in ("bn1.running_mean", "layer5.0.bn1.running_var", "layer8.0.bn2.running_mean")})
+    net.eval()
+    with torch.no_grad():
+        fx["drn_c_42"]["out_eval"] = net(x.detach())[0]
+    d22 = drn_d_22(pretrained=False, num_classes=10, pool_size=4)  # arch D with the classification head (AvgPool2d + fc)
+    seeded_fill_(d22, 611)
+    d22.eval()
+    with torch.no_grad():
+        fx["drn_d_22"] = dict(seed=611, x_seed=612, out=d22(seeded_tensor((2, 3, 32, 32), 612)))
+    torch.manual_seed(23)
+    G = ref_model.ReferenceFill(None, dict(type="drn", img_f=16), dict(ngf=8, z_nc=16, img_f=32, layers=5, norm="instance", activation="LeakyReLU", L=0),
+                                use_att=True, out_size=(64, 64))
+    seeded_fill_(G.src_encoder, 621)
+    seeded_fill_(G.ref_encoder, 622)
+    G.eval()
+    dec_sd = {k: v.clone() for k, v in sd_clone(G).items() if not (k.startswith("src_encoder.") or k.startswith("ref_encoder."))}
+    g = torch.Generator().manual_seed(63)
+    src, rf = torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 3, 64, 64, generator=g)
+    mask = (torch.rand(2, 64, 64, generator=g) < 0.4).float()
+    with torch.no_grad():
+        o = G(src, rf, src_mask=mask)
+    fx["reference_fill_drn"] = dict(enc_seeds=(621, 622), rest_sd=dec_sd, src=src, ref=rf, mask=mask, out=o)
+    torch.save(fx, os.path.join(OUT, "drn.pt"))
+    print("drn: out", tuple(out.shape), "fill", tuple(o.shape), "%.2f MB" % (os.path.getsize(os.path.join(OUT, "drn.pt")) / 1e6))
+
+
+if __name__ == "__main__":
+    drn_fixture()

@@ -43,30 +43,32 @@ def pack(w):
     return wf, wt
 
 
-def desc(x, w, stride, pad, pad_mode=0, x_cs=None, y_cs=None):
+def desc(x, w, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1):
     n, c, h, wd = x.shape
     k, _, kh, kw = w.shape
-    oh = (h + 2 * pad - kh) // stride + 1
-    ow = (wd + 2 * pad - kw) // stride + 1
-    return _lib.ConvDesc(n, h, wd, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode), oh, ow
+    oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ow = (wd + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    return _lib.ConvDesc(n, h, wd, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode, dil), oh, ow
 
 
-CASES = [  # n, c, k, h, w, ksz, stride, pad
-    (2, 8, 12, 9, 7, 3, 1, 1), (1, 3, 8, 10, 11, 3, 1, 1), (2, 16, 5, 6, 6, 1, 1, 0), (2, 8, 4, 12, 10, 3, 2, 1),
-    (1, 4, 6, 9, 8, 4, 2, 1), (2, 8, 1, 7, 7, 3, 1, 0), (1, 6, 3, 8, 8, 3, 1, 1), (1, 8, 8, 11, 9, 1, 2, 0),
+CASES = [  # n, c, k, h, w, ksz, stride, pad, dilation
+    (2, 8, 12, 9, 7, 3, 1, 1, 1), (1, 3, 8, 10, 11, 3, 1, 1, 1), (2, 16, 5, 6, 6, 1, 1, 0, 1), (2, 8, 4, 12, 10, 3, 2, 1, 1),
+    (1, 4, 6, 9, 8, 4, 2, 1, 1), (2, 8, 1, 7, 7, 3, 1, 0, 1), (1, 6, 3, 8, 8, 3, 1, 1, 1), (1, 8, 8, 11, 9, 1, 2, 0, 1),
+    # dilated 3x3 convolutions of modules/drn.py (stride 1, padding = dilation), and a 7x7 stem
+    (2, 8, 12, 11, 9, 3, 1, 2, 2), (1, 16, 8, 13, 12, 3, 1, 4, 4), (1, 4, 6, 9, 9, 3, 1, 2, 2), (1, 3, 8, 12, 10, 7, 1, 3, 1),
 ]
 
 
-@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", CASES)
-def test_conv_fwd_dgrad_wgrad(emu, n, c, k, h, w, ksz, stride, pad):
+@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad,dil", CASES)
+def test_conv_fwd_dgrad_wgrad(emu, n, c, k, h, w, ksz, stride, pad, dil):
     g = torch.Generator().manual_seed(h * 100 + c)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
     wt_ = torch.randn(k, c, ksz, ksz, generator=g, requires_grad=True)
     b = torch.randn(k, generator=g)
-    y = F.conv2d(x, wt_, b, stride=stride, padding=pad)
+    y = F.conv2d(x, wt_, b, stride=stride, padding=pad, dilation=dil)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
-    d, oh, ow = desc(x, wt_, stride, pad)
+    d, oh, ow = desc(x, wt_, stride, pad, dil=dil)
     wf, wtp = pack(wt_.detach())
     xh, gyh = nhwc(x.detach()), nhwc(gy)
     res = torch.randn(n, oh, ow, k, generator=g)
