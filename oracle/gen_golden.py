@@ -664,10 +664,15 @@ def psp_whole_fixture():
                 "encoder.input_layer.1.running_mean", "encoder.input_layer.1.running_var", "encoder.input_layer.1.num_batches_tracked",
                 "encoder.body.0.res_layer.0.running_var", "encoder.body.7.shortcut_layer.1.running_mean",
                 "encoder.body.23.res_layer.4.running_mean", "encoder.body.23.res_layer.4.running_var")}
+            # eval mode (frozen BatchNorm statistics): the well-conditioned form of the same backward, for a strict comparison
             net.eval()
-            with torch.no_grad():
-                img_e = net(x.detach(), ref=ref.detach(), src_mask=mask, resize=True, randomize_noise=False)
-            fx["image_eval"] = grad_digest(img_e, 16384)
+            net.zero_grad()
+            xe, re = x.detach().clone().requires_grad_(True), ref.detach().clone().requires_grad_(True)
+            img_e, lat_e = net(xe, ref=re, src_mask=mask, resize=True, randomize_noise=False, return_latents=True)
+            ((img_e * seeded_tensor(img_e.shape, 33)).sum() / 256.0 + (lat_e * seeded_tensor(lat_e.shape, 34)).sum()).backward()
+            fx["image_eval"] = grad_digest(img_e.detach(), 16384)
+            fx["eval"] = dict(latent=lat_e.detach().clone(), gx=grad_digest(xe.grad, 8192), gref=grad_digest(re.grad, 8192),
+                              gparams={n: grad_digest(p.grad, 256) for n, p in net.named_parameters() if p.grad is not None})
             print("psp_whole: image range", float(img.min()), float(img.max()), "latent std", float(lat.std()))
         del net
     torch.save(fx, os.path.join(OUT, "psp_whole.pt"))
@@ -984,9 +989,14 @@ def drn_fixture():
     fx["drn_c_42"] = dict(seed=601, x_seed=602, cot_seed=603, out=out.detach().clone(), mids=[grad_digest(m, 4096) for m in mids], gx=x.grad.clone(),
                           gparams={n: grad_digest(p.grad, 256) for n, p in net.named_parameters() if p.grad is not None},
                           stats_after={k: sd[k].clone() for k in ("bn1.running_mean", "layer5.0.bn1.running_var", "layer8.0.bn2.running_mean")})
+    # eval mode (frozen BatchNorm statistics: no batch-of-2 variance in the backward) for the strict gradient comparison
     net.eval()
-    with torch.no_grad():
-        fx["drn_c_42"]["out_eval"] = net(x.detach())[0]
+    net.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    oe = net(x2)[0]
+    (oe * seeded_tensor(oe.shape, 603)).sum().backward()
+    fx["drn_c_42"].update(out_eval=oe.detach().clone(), gx_eval=x2.grad.clone(),
+                          gparams_eval={n: grad_digest(p.grad, 256) for n, p in net.named_parameters() if p.grad is not None})
     d22 = drn_d_22(pretrained=False, num_classes=10, pool_size=4)  # arch D with the classification head (AvgPool2d + fc)
     seeded_fill_(d22, 611)
     d22.eval()

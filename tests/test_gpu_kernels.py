@@ -94,22 +94,28 @@ CONV_CASES = [  # n, c, k, h, w, ksz, stride, pad
     # stride-2 adjoints of small maps with a deep reduction (the pSp style heads, psp_encoders.py:13-36): split over workgroups, all
     # sub-pixel phases add into one initialised output (incl. phases of odd extents and the 2x2 -> 1x1 case)
     (4, 512, 256, 8, 8, 3, 2, 1), (2, 256, 512, 5, 7, 3, 2, 1), (8, 512, 512, 2, 2, 3, 2, 1),
+    # dilated 3x3 convolutions of modules/drn.py (padding = dilation; a 9th entry = the dilation) on the LDS-DMA and the register path,
+    # and the 7x7 / 11x11-stride-4 stems of DRN and LPIPS' AlexNet
+    (2, 256, 256, 8, 6, 3, 1, 2, 2), (2, 512, 512, 8, 6, 3, 1, 4, 4), (2, 64, 48, 17, 15, 3, 1, 2, 2), (2, 8, 12, 11, 9, 3, 1, 2, 2),
+    (2, 3, 16, 64, 48, 7, 1, 3), (2, 3, 64, 63, 63, 11, 4, 2),
 ]
 
 
-@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", CONV_CASES)
-def test_conv_family(dev, FF, n, c, k, h, w, ksz, stride, pad):
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_family(dev, FF, case):
     from face_mask_inpaint_amd import _lib
 
+    n, c, k, h, w, ksz, stride, pad = case[:8]
+    dil = case[8] if len(case) > 8 else 1
     lib = _lib.lib()
     g = torch.Generator().manual_seed(h * 100 + c)
     x = torch.randn(n, c, h, w, generator=g, requires_grad=True)
     wt_ = (torch.randn(k, c, ksz, ksz, generator=g) / (c * ksz * ksz) ** 0.5).requires_grad_(True)
     b = torch.randn(k, generator=g)
-    y = F.conv2d(x, wt_, b, stride=stride, padding=pad)
+    y = F.conv2d(x, wt_, b, stride=stride, padding=pad, dilation=dil)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
-    d, oh, ow = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad)
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad, dil=dil)
     wf, wtp = [t.to(dev) for t in pack(wt_.detach())]
     xh, gyh, bd = nhwc(x.detach()).to(dev), nhwc(gy).to(dev), b.to(dev)
     res = torch.randn(n, oh, ow, k, generator=g)
