@@ -91,10 +91,10 @@ def digest_error(g: torch.Tensor, d64: dict) -> float:
     return float((f[::int(d64["step"])] - d64["sample"]).abs().max()) / (float(d64["max"]) + 1e-30)
 
 
-def check_adjudicated(grads: dict, d32: dict, d64: dict, floor: float = 2e-3, what: str = "", med_factor: float = 2.0) -> None:
+def check_adjudicated(grads: dict, d32: dict, d64: dict, floor: float = 2e-3, what: str = "", med_factor: float = 2.0, p90_factor: float = 3.0) -> None:
     """gradients (name -> tensor) against the reference's FLOAT64 digests, bounded by the error DISTRIBUTION of the reference's
     OWN fp32 run against the same float64 values (errors relative to each tensor's largest entry):
-        median <= med_factor (2) x the reference's median,  90th percentile <= 3 x the reference's,  worst <= max(4 x the reference's worst, floor)
+        median <= med_factor (2) x the reference's median,  90th percentile <= p90_factor (3) x the reference's,  worst <= max(4 x the reference's worst, floor)
     (with fewer than 8 tensors: every tensor <= max(4 x the reference's worst, floor)).
     Why a distribution and not a per-tensor bound: end-to-end gradients of these networks are decided at the 1e-3 .. 1e-2 level by
     chance events that differ between ANY two fp32 evaluations -- PReLU / LeakyReLU kink flips of pre-activations below the forward
@@ -116,7 +116,7 @@ def check_adjudicated(grads: dict, d32: dict, d64: dict, floor: float = 2e-3, wh
     assert err[-1][0] <= worst_lim, msg
     if len(err) >= 8:
         assert q(err, .5)[0] <= med_factor * q(ref, .5) + 1e-6, msg
-        assert q(err, .9)[0] <= 3 * q(ref, .9) + 1e-6, msg
+        assert q(err, .9)[0] <= p90_factor * q(ref, .9) + 1e-6, msg
 
 
 def as_digest(t: torch.Tensor) -> dict:
