@@ -129,3 +129,133 @@ def test_two_rank_early_discriminator_schedule(tmp_path):
     for net, m in (("G", G), ("D", D)):
         for k, v in m.state_dict().items():
             torch.testing.assert_close(a[net][k], v, rtol=1e-5, atol=1e-6, msg=lambda s, k=k: f"{net}.{k}: {s}")
+
+
+class _StubVGG(torch.nn.Module):
+    """CPU stand-in for VGGLoss.forward_multi (the HIP feature extractor cannot run here): smooth per-term losses of the same
+    arguments, so that GANOptimizer.__call__ -- the schedule under test -- runs unmodified"""
+
+    def forward_multi(self, jobs):
+        return [((a - b).square().mean() if kind == "perceptual" else (a.mean(dim=(2, 3)) - b.mean(dim=(2, 3))).abs().mean()) for a, b, kind in jobs]
+
+
+def _cpu_gan_optimizer(optD, optG):
+    from face_mask_inpaint_amd.modules.loss import GANOptimizer
+
+    class CpuGANOptimizer(GANOptimizer):  # only the HIP-backed loss terms are replaced; __call__ is the product's
+        @staticmethod
+        def _masked(img, mask, invert):
+            m = mask.unsqueeze(1)
+            return img * ((1 - m) if invert else m)
+
+        def discriminator_loss(self, netD, real, fake):
+            return 0.5 * ((netD(real) - 1).square().mean() + netD(fake.detach()).square().mean())
+
+        def generator_loss(self, netD, real, fake, freeze=True):
+            return (netD(fake) - 1).square().mean() * self.lambda_g + (fake - real).abs().mean()
+
+    gopt = CpuGANOptimizer(optD, optG, vgg_width_div=16)
+    gopt.vgg_loss = _StubVGG()
+    return gopt
+
+
+def _conv_nets():
+    torch.manual_seed(0)
+    G = torch.nn.Sequential(torch.nn.Conv2d(6, 8, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(8, 3, 3, padding=1))
+    D = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.LeakyReLU(0.1),
+                            torch.nn.Conv2d(8, 1, 3))
+    D.alpha = torch.nn.Parameter(torch.zeros(1))  # Auto_Attn.alpha-like: never receives a gradient
+    return G, D
+
+
+def _gan_batch(rank):
+    g = torch.Generator().manual_seed(200 + rank)
+    src, ref, gt = (torch.rand(3, 3, 12, 12, generator=g) for _ in range(3))
+    return src, ref, gt, (torch.rand(3, 12, 12, generator=g) < 0.4).float()
+
+
+def _real_gan_worker(rank, world, port, out):
+    """the product's GANOptimizer.__call__ (early-discriminator branch, chosen automatically because the optimisers are
+    DataParallelOptimizer) with a D bucket size that makes the hooks launch buckets in the MIDDLE of the D backward and leaves a
+    remainder for launch()"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from face_mask_inpaint_amd import distributed as fd
+
+    G, D = _conv_nets()
+    fd.broadcast_parameters([G, D])
+    og = fd.DataParallelOptimizer(torch.optim.Adam(G.parameters(), lr=1e-2), bucket_bytes=1024)
+    od = fd.DataParallelOptimizer(torch.optim.Adam(D.parameters(), lr=1e-2), bucket_bytes=1500)  # 3 conv layers: 896 + 2336 + 292 bytes
+    gopt = _cpu_gan_optimizer(od, og)
+    assert gopt.early_d is None  # automatic
+    src, ref, gt, mask = _gan_batch(rank)
+    sent_mid_backward = []
+    orig_launch = od.launch
+
+    def launch():
+        sent_mid_backward.append(len(od._inflight))  # buckets already in flight when launch() runs (the hooks call it for full buckets too)
+        return orig_launch()
+
+    od.launch = launch
+    losses = []
+    for _ in range(2):
+        gen = G(torch.cat([src, ref], 1))
+        losses.append([float(v) for v in gopt(D, src, gt, ref, gen, mask)])
+    # per step: two hook-driven launches inside the D backward (0, then 1 bucket in flight), then GANOptimizer's explicit launch()
+    # of the remainder with 2 in flight -- a D bucket boundary fell inside the D backward
+    assert sent_mid_backward[:3] == [0, 1, 2], sent_mid_backward
+    assert od.collectives >= 4 and og.collectives >= 2
+    # a backward without a step (validation / skipped step) must not poison the next step: zero_grad drops its buckets
+    gen = G(torch.cat([src, ref], 1))
+    (D(gen)).mean().backward()
+    assert od._inflight or od._open
+    od.zero_grad(set_to_none=True)
+    og.zero_grad(set_to_none=True)
+    assert not od._inflight and not od._open
+    gen = G(torch.cat([src, ref], 1))
+    losses.append([float(v) for v in gopt(D, src, gt, ref, gen, mask)])
+    torch.save({"G": G.state_dict(), "D": D.state_dict(), "losses": losses}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_real_gan_optimizer_early_discriminator_two_ranks(tmp_path):
+    port, out = _free_port(), str(tmp_path / "rgan")
+    mp.spawn(_real_gan_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    for net in ("G", "D"):
+        for k in a[net]:
+            assert torch.equal(a[net][k], b[net][k]), (net, k)
+    # one process, reference order (early_d off), on the union of the two shards (mean over the ranks of every loss)
+    G, D = _conv_nets()
+    og, od = torch.optim.Adam(G.parameters(), lr=1e-2), torch.optim.Adam(D.parameters(), lr=1e-2)
+
+    class Both:  # evaluates the per-rank mean losses of both shards: the sum of gradients / 2 equals the all-reduced average
+        pass
+
+    gopt = _cpu_gan_optimizer(od, og)
+    gopt.early_d = False
+    batches = [_gan_batch(0), _gan_batch(1)]
+    for it in range(3):
+        # G step
+        gens = [G(torch.cat([s, r], 1)) for s, r, _, _ in batches]
+        g_total = 0
+        for gen, (src, ref, gt, mask) in zip(gens, batches):
+            for p in D.parameters():
+                p.requires_grad_(False)
+            gl = gopt.generator_loss(D, gt, gen, freeze=False)
+            for p in D.parameters():
+                p.requires_grad_(True)
+            perc, sty, cx = gopt.vgg_loss.forward_multi([(gen, gt, "perceptual"), (gopt._masked(gen, mask, True), src, "style"),
+                                                         (gopt._masked(gen, mask, False), gopt._masked(ref, mask, False), "contextual")])
+            g_total = g_total + (gl + perc * gopt.lambda_perc + sty * gopt.lambda_style + cx * gopt.lambda_cx) / 2
+        og.zero_grad()
+        g_total.backward()
+        og.step()
+        d_total = sum(gopt.discriminator_loss(D, gt, gen) for gen, (_, _, gt, _) in zip(gens, batches)) / 2
+        od.zero_grad()
+        d_total.backward()
+        od.step()
+    for net, m in (("G", G), ("D", D)):
+        for k, v in m.state_dict().items():
+            torch.testing.assert_close(a[net][k], v, rtol=1e-5, atol=1e-6, msg=lambda s, k=k: f"{net}.{k}: {s}")
+    assert float(a["D"]["alpha"]) == 0.0
