@@ -227,7 +227,11 @@ def test_c2_model_full_size_against_oracle(dev):
     err = float((gen.detach().cpu() - ogen).abs().max())
     assert err <= 1e-3 * float(ogen.abs().max()), f"image: {err:.3e}"
     for name, a, b in zip(("d_loss", "g_loss", "perceptual", "style", "contextual"), got, want[1:]):
-        assert abs(a - float(b)) <= 1e-3 * abs(float(b)) + 1e-12, f"{name}: {a:.6e} vs {float(b):.6e}"
+        # the contextual term normalises cosine distances by (row minimum + 1e-5) (external_function.py:262): the masked-out pixels of
+        # both images are identical, so the minimum is ~0 and an absolute 1e-7 in a distance is 1e-2 in the exponent -- run to run the
+        # HIP value itself moves by ~1e-3 relative (fp32 atomics in split reductions)
+        tol = 5e-3 if name == "contextual" else 1e-3
+        assert abs(a - float(b)) <= tol * abs(float(b)) + 1e-12, f"{name}: {a:.6e} vs {float(b):.6e}"
     sd = {**{"G." + k: v for k, v in G.state_dict().items()}, **{"D." + k: v for k, v in D.state_dict().items()}}
     for k in ("G.decoder.decoder4.conv2.module.weight_u", "G.src_encoder.prior.conv1.module.weight_v", "D.block0.conv1.module.weight_u", "D.block5.conv2.module.weight_v"):
         P = PG if k.startswith("G.") else PD
