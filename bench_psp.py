@@ -117,10 +117,13 @@ LOSS_ARGS = dict(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpi
                  start_from_latent_avg=True)
 
 
-def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None):
+def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None, graph=False):
     """one train_psp.py step loop (train_psp.py:307-335): pSp forward (GradualStyleEncoder on src + ref with attention, StyleGAN2
     decoder of ``size``), pSpLoss, backward, fused Adam over the encoder (+ decoder when train_decoder, as scripts/train_psp.sh runs
-    it).  Returns (seconds for ``steps`` steps, per-launch summary of one extra profiled step)."""
+    it).  Returns (seconds for ``steps`` steps, per-launch summary of one extra profiled step).
+    ``graph=True``: the whole step (forward, loss, backward, optimiser) is captured ONCE in a HIP graph (torch.cuda.graph) and
+    replayed -- ~5 500 launches per step are CPU-bound at 4 images per GPU; the captured work is identical (fresh N(0,1) noise per
+    replay from the graph-safe generator, device-side Adam step count, loss values read back after the replay)."""
     from face_mask_inpaint_amd import functional as FF
     from face_mask_inpaint_amd.modules.psp.criteria import pSpLoss
     from face_mask_inpaint_amd.modules.psp.psp import pSp
@@ -134,10 +137,11 @@ def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, 
     crit = pSpLoss(types.SimpleNamespace(**(loss_args or LOSS_ARGS)))
     if hasattr(crit, "to"):
         crit = crit.to(dev)
+    crit.defer_logs = graph
     params = [p for p in net.encoder.parameters() if p.requires_grad]
     if train_decoder:
         params += [p for p in net.decoder.parameters() if p.requires_grad]
-    opt = FusedAdam(params, lr=1e-4)
+    opt = FusedAdam(params, lr=1e-4, capturable=graph)
     x, ref, y, m = synth(batch, dev)
 
     def step():
@@ -148,8 +152,22 @@ def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, 
         opt.step()
         return loss
 
-    for _ in range(warmup):
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator pools, lazily created state), as capture requires
+            for _ in range(max(warmup, 2)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_loss = step()
+        eager_step, step = step, lambda: (g.replay(), static_loss)[1]
         step()
+    else:
+        for _ in range(warmup):
+            step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -157,6 +175,8 @@ def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, 
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss).item()
+    if graph:
+        step = eager_step  # the profiled step below brackets every launch with events: eager
     FF.PROFILE = []
     step()
     torch.cuda.synchronize()

@@ -297,6 +297,51 @@ extern "C" int fmi_adam_step_f32(const fmi_adam_entry* entries, int count, int64
   return fmi_launch_status();
 }
 
+// The same update with the step count in DEVICE memory (incremented by the launch sequence itself): nothing about the step is baked
+// into the launch arguments, so a training step captured in a HIP graph replays with the right bias corrections.
+__global__ void adam_step_inc_kernel(int* step) { step[0] += 1; }
+__global__ void __launch_bounds__(256) adam_dev_kernel(const AdamArgs args, float lr, float beta1, float beta2, float eps, float wd,
+                                                       const int* __restrict__ step) {
+  const fmi_adam_entry e = args.e[blockIdx.y];
+  const int64_t base = (int64_t)blockIdx.x * ADAM_CHUNK;
+  if (base >= e.n) return;
+  const int st = step[0];
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)st));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st));
+  const float step_size = lr / bc1;
+  for (int64_t i = base + threadIdx.x; i < base + ADAM_CHUNK && i < e.n; i += 256) {
+    float g = e.g[i];
+    const float p = e.p[i];
+    if (wd != 0.f) g += wd * p;
+    const float m = e.m[i] + (g - e.m[i]) * (1.f - beta1);
+    const float v = e.v[i] * beta2 + (1.f - beta2) * (g * g);
+    e.m[i] = m;
+    e.v[i] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    e.p[i] = p - step_size * (m / denom);
+  }
+}
+extern "C" int fmi_adam_step_dev_f32(const fmi_adam_entry* entries, int count, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int* step_dev, void* stream) {
+  if (!entries || count <= 0 || !step_dev) return FMI_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  for (int base = 0; base < count; base += ENTRY_CHUNK * 2) {
+    AdamArgs a;
+    const int n = count - base < ENTRY_CHUNK * 2 ? count - base : ENTRY_CHUNK * 2;
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+      a.e[i] = entries[base + i];
+      if (!a.e[i].p || !a.e[i].g || !a.e[i].m || !a.e[i].v || a.e[i].n <= 0) return FMI_ERR_BAD_ARG;
+      if (a.e[i].n > mx) mx = a.e[i].n;
+    }
+    const int64_t gx = ceil_div64(mx, ADAM_CHUNK);
+    if (gx > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, n), dim3(256), 0, st, a, lr, beta1, beta2, eps, weight_decay, (const int*)step_dev);
+  }
+  return fmi_launch_status();
+}
+
 // ---- multi-tensor Ranger = RAdam + Lookahead + gradient centralisation (modules/psp/ranger.py:92-184) ----------------------
 // launch 1 (tensors of more than gc_dim dimensions): mean[r] of every gradient row; launch 2: the element-wise update in the
 // reference's order -- g -= mean[row]; v = v beta2 + (1 - beta2) g g; m = m beta1 + (1 - beta1) g; weight decay; p -= step_size lr

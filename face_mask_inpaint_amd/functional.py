@@ -64,7 +64,9 @@ class _ZeroSlab:
         for d in shape:
             numel *= int(d)
         nbytes = numel * torch.empty((), dtype=dtype).element_size()
-        if nbytes > cls.MAX_BYTES or nbytes == 0 or device.type != "cuda":
+        # under HIP-graph capture every accumulator must be zeroed INSIDE the graph (a memset node per replay): a slab slice is zero
+        # only the first time it is handed out
+        if nbytes > cls.MAX_BYTES or nbytes == 0 or device.type != "cuda" or torch.cuda.is_current_stream_capturing():
             return torch.zeros(shape, device=device, dtype=dtype)
         nbytes_al = (nbytes + 255) & ~255
         if cls.buf is None or cls.buf.device != device or cls.off + nbytes_al > cls.SLAB_BYTES:
@@ -1735,8 +1737,20 @@ class _BiasAdd(torch.autograd.Function):
 # multi-tensor Adam
 # ---------------------------------------------------------------------------------------------------
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay=0.0):
+    """step: python int (bias corrections computed on the host), or a 1-element int32 DEVICE tensor holding the number of steps taken
+    so far (incremented by the launch; graph-capturable)"""
     n = len(params)
     if n == 0:
+        return
+    if torch.is_tensor(step):
+        if step.dtype != torch.int32 or not step.is_cuda or step.numel() != 1:
+            raise FmiError("the device step counter must be a 1-element int32 device tensor")
+        entries = (_lib.AdamEntry * n)()
+        for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+            _chk(p, g, m, v)
+            e = entries[i]
+            e.p, e.g, e.m, e.v, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        _L().adam_step_dev_f32(entries, n, lr, beta1, beta2, eps, weight_decay, C.c_void_p(step.data_ptr()), _st())
         return
     entries = (_lib.AdamEntry * n)()
     mx = 0

@@ -40,6 +40,10 @@ class IDLoss(nn.Module):
         y_hat_feats = self.extract_feats(y_hat)
         # loss = mean_i (1 - <y_hat_i, y_i>) as one reduction; the per-sample dot products are only logged
         loss = 1.0 - FF.dot_all(y_hat_feats, y_feats, 1.0 / n_samples)
+        if getattr(self, "defer_logs", False):  # no host synchronisation (HIP-graph capture): the improvement stays a device scalar
+            with torch.no_grad():
+                imp = ((y_hat_feats.detach() * y_feats).sum() - (y_feats * x_feats).sum()) / n_samples
+            return loss, imp, None
         with torch.no_grad():
             dt = (y_hat_feats.detach() * y_feats).sum(1).tolist()
             di = (y_hat_feats.detach() * x_feats).sum(1).tolist()

@@ -379,6 +379,10 @@ typedef struct {
 } fmi_adam_entry;
 int fmi_adam_step_f32(const fmi_adam_entry* entries /* HOST array */, int count, int64_t max_n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int step, void* stream);
+/* the same Adam step with the step count in device memory: step_dev[0] is incremented first, the bias corrections are computed on
+ * the device from it -- a training step captured in a HIP graph (torch.cuda.graph) replays with the right corrections */
+int fmi_adam_step_dev_f32(const fmi_adam_entry* entries /* HOST array */, int count, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int* step_dev, void* stream);
 /* multi-tensor Ranger step = RAdam + Lookahead + gradient centralisation (modules/psp/ranger.py:92-184, the --optimizer ranger of
  * train_psp.py:290-293).  row_mean (scratch, rows floats) non-NULL = centralise: g -= mean of its row (tensors with more than one
  * dimension, cols = numel / shape[0]); step_size / rectified from the host (the RAdam variance rectification depends on the step
