@@ -117,6 +117,12 @@ LOSS_ARGS = dict(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpi
                  start_from_latent_avg=True)
 
 
+# the loss of the reference's shipped training script (scripts/train_psp.sh:12-15; the *_ref lambdas keep train_psp.py's defaults of 0):
+# ArcFace ID + masked L2 + masked LPIPS(alex) in the backward, VGG style / contextual evaluated for the log only
+SCRIPT_LOSS_ARGS = dict(id_lambda=0.1, lpips_lambda=0.8, l2_lambda=2.0, style_lambda=1000.0, lpips_lambda_ref=0.0, l2_lambda_ref=0.0, cx_lambda=1.0,
+                        w_norm_lambda=0.0, start_from_latent_avg=True)
+
+
 def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None, graph=False):
     """one train_psp.py step loop (train_psp.py:307-335): pSp forward (GradualStyleEncoder on src + ref with attention, StyleGAN2
     decoder of ``size``), pSpLoss, backward, fused Adam over the encoder (+ decoder when train_decoder, as scripts/train_psp.sh runs
@@ -195,14 +201,15 @@ def extra_block(dev, steps=4, warmup=2):
     in-decoder upfirdn2d (Blur / RGB-skip Upsample, forward + backward) and fused noise+bias+lrelu in GB/s against 8 TB/s"""
     out = {}
     for key, size, batch in (("C3_train_psp_256_bf16_bs16", 256, 16), ("C5_train_psp_1024_bf16_bs4_single_gpu_leg", 1024, 4)):
-        dt, summ = train_leg(dev, "bf16", size, batch, steps, warmup, train_decoder=True)
+        dt, summ = train_leg(dev, "bf16", size, batch, steps, warmup, train_decoder=True, loss_args=SCRIPT_LOSS_ARGS, graph=True)
         mf = summ.get("mfma", {})
         out[key] = {"images_per_s": round(batch * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2),
                     "modulated_conv_bf16": {"tflops": mf.get("tflops"), "frac_of_bf16_peak": mf.get("utilisation"), "launches": mf.get("launches"),
                                             "kernel_ms": mf.get("kernel_ms"), "algorithmic_tflop": mf.get("algorithmic_tflop")},
                     "upfirdn2d_in_decoder": summ.get("upfirdn2d"), "noise_bias_act": summ.get("noise_bias_act"),
                     "config": "train_psp.py RefpSp + attention (IR-SE50 encoder fp32 on src + ref), StyleGAN2 %d^2 decoder bf16 (fp32 accumulate / master weights), "
-                              "bs %d, --train_decoder 1 as scripts/train_psp.sh, masked-L2 + reference-L2 + W-norm loss (LPIPS / ID off), fused Adam; %d timed steps" % (size, batch, steps)}
+                              "bs %d, --train_decoder 1 and the loss of scripts/train_psp.sh (ArcFace ID 0.1 + masked L2 2 + masked LPIPS-alex 0.8 in the backward; VGG style / contextual "
+                              "logged only; random-init LPIPS / ArcFace weights), fused Adam; the whole step captured once in a HIP graph and replayed; %d timed steps" % (size, batch, steps)}
     out["peaks"] = {"bf16_mfma_tflops": BF16_MFMA_PEAK, "hbm_GBps": HBM_PEAK_GBS}
     return out
 

@@ -75,7 +75,7 @@ class pSpLoss(nn.Module):
             loss = loss + loss_lpips * self.lpips_lambda
         if self.style_lambda > 0 and m is not None:
             with torch.no_grad():  # logged only in the reference (criteria/__init__.py:74-76)
-                loss_dict["loss_style"] = float(self.vgg_loss(FF.to_nchw(FF.mask_mul(yh, m, True)), x, lossType="style") * self.style_lambda)
+                loss_dict["loss_style"] = self._log(self.vgg_loss(FF.to_nchw(FF.mask_mul(yh, m, True)), x, lossType="style") * self.style_lambda)
         if ref is not None:
             rf = FF.mask_mul(FF.to_nhwc(ref), m, False)
             yhm = FF.mask_mul(yh, m, False)
@@ -89,7 +89,7 @@ class pSpLoss(nn.Module):
                 loss = loss + loss_l2_ref * self.l2_lambda_ref
             if self.cx_lambda > 0:
                 with torch.no_grad():  # logged only (criteria/__init__.py:88-90)
-                    loss_dict["loss_context"] = float(self.vgg_loss(FF.to_nchw(yhm), FF.to_nchw(rf), lossType="contextual") * self.cx_lambda)
+                    loss_dict["loss_context"] = self._log(self.vgg_loss(FF.to_nchw(yhm), FF.to_nchw(rf), lossType="contextual") * self.cx_lambda)
         if self.w_norm_lambda > 0 and latent_avg is not None:
             loss_w_norm = self.w_norm_loss(latent, latent_avg.to(latent.device))
             loss_dict["loss_w_norm"] = self._log(loss_w_norm)

@@ -75,9 +75,7 @@ class SEModule(Module):
     def nhwc(self, x):
         with weight_scope(self):
             n, h, w, c = x.shape
-            if h != w:
-                raise NotImplementedError("SEModule: square feature maps only")
-            s = FF.avg_pool(x, h)                                  # [N,1,1,C]
+            s = FF.avg_pool(x, h) if h == w else FF.adaptive_avg_pool(x, 1, 1)  # AdaptiveAvgPool2d(1) -> [N,1,1,C]
             s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
             s = FF.sigmoid(run_conv(self.fc2, s))
             return FF.scale_channels(x, s.view(n, c))

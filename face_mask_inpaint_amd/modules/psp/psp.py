@@ -75,12 +75,8 @@ class pSp(nn.Module):
                     codes[:, i] = 0
         images, result_latent = self.decoder([codes], input_is_latent=not input_code, randomize_noise=randomize_noise,
                                              return_latents=return_latents)
-        if resize:
-            x_ = FF.to_nhwc(images)
-            k = x_.shape[1] // 256
-            if x_.shape[1] % 256 or x_.shape[1] != x_.shape[2]:
-                raise NotImplementedError("face_pool is implemented for square outputs that are multiples of 256")
-            images = FF.to_nchw(FF.avg_pool(x_, k)) if k > 1 else images
+        if resize:  # self.face_pool = AdaptiveAvgPool2d((256, 256)): any decoder output size (replication below 256, psp.py:33,113-114)
+            images = FF.to_nchw(FF.adaptive_avg_pool(FF.to_nhwc(images), 256, 256))
         return (images, result_latent) if return_latents else images
 
     def set_opts(self, opts):

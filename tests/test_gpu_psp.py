@@ -238,3 +238,66 @@ def test_lpips_id_and_full_psp_loss_against_reference(dev, golden):
     loss.backward()
     check_digest(yh.grad, f["gy_hat"], 5e-3, "d loss / d y_hat")
     torch.testing.assert_close(lat.grad.cpu(), f["glatent"], rtol=1e-3, atol=1e-8)
+
+
+def test_train_step_captured_in_a_hip_graph_equals_eager(dev):
+    """the whole train_psp step (pSp forward, pSpLoss, backward, FusedAdam) captured once with torch.cuda.graph and replayed must do
+    what the eager loop does: same losses step by step (fixed noise buffers; device-side Adam step count, accumulators zeroed inside
+    the graph, deferred loss logs).  bench.py's C5 leg runs this way (5 500 launches per step are CPU-bound at 4 images per GPU)."""
+    from face_mask_inpaint_amd.modules.psp.criteria import pSpLoss
+    from face_mask_inpaint_amd.modules.psp.psp import pSp
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    def run(graph, n_steps=4):
+        torch.manual_seed(11)
+        opts = types.SimpleNamespace(output_size=64, encoder_type="GradualStyleEncoder", train_decoder=True, use_attention=True, pt_ckpt_path=None,
+                                     stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype="bf16")
+        net = pSp(opts).to(dev).train()
+        net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
+        crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
+                                             w_norm_lambda=0.005, start_from_latent_avg=True))
+        crit.defer_logs = True
+        opt = FusedAdam([p for p in net.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+        g = torch.Generator().manual_seed(5)
+        x, ref, y = (torch.rand(2, 3, 256, 256, generator=g).to(dev) * 2 - 1 for _ in range(3))
+        m = torch.zeros(2, 256, 256, device=dev)
+        m[:, 100:220, 60:200] = 1
+
+        def step():
+            y_hat, latent = net(x, ref=ref, src_mask=m, return_latents=True, randomize_noise=False)
+            loss, ld, _ = crit(x, y, y_hat, latent, latent_avg=net.latent_avg, ref=ref, mask=m)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+
+        losses = []
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    losses.append(float(step()))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                static_loss = step()
+            for _ in range(n_steps - 2):
+                cg.replay()
+                losses.append(float(static_loss))
+        else:
+            for _ in range(n_steps):
+                losses.append(float(step()))
+        step_count = int(opt.param_groups[0]["step_dev"])
+        w = net.encoder.styles[0].linear.weight.detach().float().cpu().clone()
+        return losses, step_count, w
+
+    le, se, we = run(False)
+    lg, sg, wg = run(True)
+    assert se == sg == 4  # the capture itself executes nothing; every replay advances the device-side step count
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    assert le[-1] != le[0]  # the optimiser really moved the weights
+    # Adam's update is lr * g / (|g| + eps)-like in the first steps: elements whose gradient is rounding noise may move by lr in either run
+    assert float((we - wg).abs().max()) <= 4 * 1e-4 + 1e-6
