@@ -1656,20 +1656,26 @@ def subsample(x, stride):
 
 class _BatchNormTrain(torch.autograd.Function):
     """BatchNorm2d (training statistics) on NHWC: statistics over (N, H, W) per channel = the instance-norm kernels with the
-    batch folded into the pixel axis.  Returns (y, stats[1][C][2] = (mean, rstd), sums[1][C][2] = fp64 (sum, sum of squares))."""
+    batch folded into the pixel axis.  ``groups`` > 1: the batch consists of that many equal parts that were SEPARATE forward
+    calls in the reference (the source and the reference image of GradualStyleEncoder.forward, psp_encoders.py:101-125) -- each part
+    gets its own statistics, exactly as if the parts had been normalised one after the other.
+    Returns (y, stats[G][C][2] = (mean, rstd), sums[G][C][2] = fp64 (sum, sum of squares))."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, groups=1):
         _chk(x, gamma, beta)
         lib = _L()
         c = x.shape[-1]
-        rows = x.numel() // c
-        sums, ws = _norm_ws(x.device, 1, c)
-        stats = torch.empty((1, c, 2), device=x.device, dtype=torch.float32)
-        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), 1, rows, c, eps, C.c_void_p(ws.data_ptr()), ws.numel(), _st())
+        if x.shape[0] % groups:
+            raise FmiError("grouped BatchNorm: the batch does not divide into the groups")
+        rows = x.numel() // c // groups
+        sums, ws = _norm_ws(x.device, groups, c)
+        stats = torch.empty((groups, c, 2), device=x.device, dtype=torch.float32)
+        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), groups, rows, c, eps, C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         y = torch.empty_like(x)
-        lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), 1, rows, c, 1.0, _st())
+        lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), groups, rows, c, 1.0, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
+        ctx.groups = groups
         ctx.mark_non_differentiable(stats, sums)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output (one fill launch per BatchNorm and step)
         return y, stats, sums
@@ -1679,15 +1685,16 @@ class _BatchNormTrain(torch.autograd.Function):
         lib = _L()
         x, stats, gamma, beta = ctx.saved_tensors
         c = x.shape[-1]
-        rows = x.numel() // c
+        groups = ctx.groups
+        rows = x.numel() // c // groups
         g = g.contiguous()
-        red, ws = _norm_ws(x.device, 1, c)
-        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), 1, rows, c, 1.0,
+        red, ws = _norm_ws(x.device, groups, c)
+        lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), groups, rows, c, 1.0,
                                     C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
         lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
-                                   1, rows, c, 1.0, _st())
-        return gx, dg, db, None
+                                   groups, rows, c, 1.0, _st())
+        return gx, dg, db, None, None
 
 
 def batch_norm_running_update(stats, running_mean, running_var, num_batches_tracked, count, eps, momentum, sums=None):
@@ -1702,8 +1709,25 @@ def batch_norm_running_update(stats, running_mean, running_var, num_batches_trac
                                       _p(running_var), nbt, running_mean.numel(), int(count), float(eps), float(momentum), _st())
 
 
-def batch_norm_train(x, gamma, beta, eps=1e-5):
-    return _BatchNormTrain.apply(x, gamma, beta, float(eps))
+def batch_norm_train(x, gamma, beta, eps=1e-5, groups=1):
+    return _BatchNormTrain.apply(x, gamma, beta, float(eps), int(groups))
+
+
+class _SplitBatch(torch.autograd.Function):
+    """x[:n], x[n:] as views; the two gradients are joined by one copy"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat([ga, gb], dim=0), None
+
+
+def split_batch(x, n):
+    return _SplitBatch.apply(x, int(n))
 
 
 def channel_affine(x, scale, shift):

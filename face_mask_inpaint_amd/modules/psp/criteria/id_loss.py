@@ -23,6 +23,10 @@ class IDLoss(nn.Module):
             print("IDLoss: %s not found -> keeping the random initialisation" % model_paths["ir_se50"])
         self.face_pool = torch.nn.AdaptiveAvgPool2d((112, 112))
         self.facenet.eval()
+        # the reference leaves the ArcFace parameters trainable but hands them to no optimiser: their gradients are computed and
+        # dropped; here they are not computed (values of everything that is used are identical)
+        for p in self.facenet.parameters():
+            p.requires_grad_(False)
 
     def train(self, mode=True):  # the reference builds IDLoss().eval() and never switches it back (criteria/__init__.py:32)
         return super().train(False)
@@ -34,9 +38,9 @@ class IDLoss(nn.Module):
 
     def forward(self, y_hat, y, x):
         n_samples = x.shape[0]
-        with torch.no_grad():
-            x_feats = self.extract_feats(x)
-            y_feats = self.extract_feats(y)
+        with torch.no_grad():  # eval-mode network, no batch-coupled op: x and y go through as one batch of 2N
+            xy = self.extract_feats(torch.cat([x, y], dim=0))
+            x_feats, y_feats = xy[:n_samples], xy[n_samples:]
         y_hat_feats = self.extract_feats(y_hat)
         # loss = mean_i (1 - <y_hat_i, y_i>) as one reduction; the per-sample dot products are only logged
         loss = 1.0 - FF.dot_all(y_hat_feats, y_feats, 1.0 / n_samples)

@@ -35,24 +35,32 @@ def get_blocks(num_layers):
     return [get_block(64, 64, u[0]), get_block(64, 128, u[1]), get_block(128, 256, u[2]), get_block(256, 512, u[3])]
 
 
+# > 1 while a module runs a batch made of that many parts that are SEPARATE forward calls in the reference (GradualStyleEncoder runs
+# its body on the source and then on the reference image): training-mode BatchNorm then normalises and updates per part, in order
+BN_GROUPS = [1]
+
+
 def batch_norm(bn: BatchNorm2d, x):
     """nn.BatchNorm2d forward on NHWC with torch's training / eval semantics"""
     if bn.training or not bn.track_running_stats:
-        y, stats, sums = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps)
+        groups = BN_GROUPS[0]
+        y, stats, sums = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps, groups)
         if bn.training and bn.track_running_stats:
-            cnt = x.numel() // x.shape[-1]
-            if bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
-                with torch.no_grad():  # one launch: momentum update of both buffers and the batch counter
-                    FF.batch_norm_running_update(stats, bn.running_mean, bn.running_var, bn.num_batches_tracked, cnt, bn.eps, bn.momentum, sums)
-                return y
-            with torch.no_grad():  # cumulative moving average (momentum=None): [C]-sized torch bookkeeping
-                mean = stats[0, :, 0]
-                m64 = sums[0, :, 0] / cnt
-                var = ((sums[0, :, 1] / cnt - m64 * m64).clamp_min(0) * (cnt / max(cnt - 1, 1))).float()
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                bn.running_var.mul_(1 - m).add_(var, alpha=m)
-                bn.num_batches_tracked += 1
+            cnt = x.numel() // x.shape[-1] // groups
+            for g in range(groups):  # the running statistics see the parts one after the other, as the reference's separate calls do
+                st, sm = stats[g:g + 1], sums[g:g + 1]
+                if bn.momentum is not None and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous():
+                    with torch.no_grad():  # one launch: momentum update of both buffers and the batch counter
+                        FF.batch_norm_running_update(st, bn.running_mean, bn.running_var, bn.num_batches_tracked, cnt, bn.eps, bn.momentum, sm)
+                    continue
+                with torch.no_grad():  # cumulative moving average (momentum=None): [C]-sized torch bookkeeping
+                    mean = st[0, :, 0]
+                    m64 = sm[0, :, 0] / cnt
+                    var = ((sm[0, :, 1] / cnt - m64 * m64).clamp_min(0) * (cnt / max(cnt - 1, 1))).float()
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var, alpha=m)
+                    bn.num_batches_tracked += 1
         return y
     # eval mode: frozen statistics, but the affine parameters still receive gradients like torch.nn.BatchNorm2d's do
     # ([C]-sized torch bookkeeping; the per-pixel work and its reductions are the library's)

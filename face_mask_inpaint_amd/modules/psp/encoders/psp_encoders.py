@@ -13,6 +13,7 @@ from ....weights import weight_scope
 from ...example_guided_att import ExampleGuidedAttention
 from ...pluralistic_model.external_function import run_conv
 from ..stylegan2.model import EqualLinear
+from . import helpers
 from .helpers import batch_norm, bottleneck_IR, bottleneck_IR_SE, get_blocks
 
 
@@ -85,10 +86,19 @@ class GradualStyleEncoder(Module):
 
     def forward(self, x, ref=None, mask=None):
         with weight_scope(self):
-            c1, c2, c3 = self._pyramid(FF.to_nhwc(x))
             if ref is not None:
                 assert mask is not None, "ref and mask should both be provided"
-                r1, r2, r3 = self._pyramid(FF.to_nhwc(ref))
+                # psp_encoders.py:101-125 runs input_layer + body on x and then AGAIN on ref (shared weights).  Here both go through
+                # as ONE batch of 2N -- every convolution launch has twice the rows (the 256-channel 32^2 stage is 256 tiles = one
+                # workgroup per CU at N = 16) and half the launches -- while training-mode BatchNorm keeps per-part statistics and
+                # updates its running buffers part by part (helpers.BN_GROUPS), so every value equals the two-pass form
+                nb = x.shape[0]
+                helpers.BN_GROUPS[0] = 2
+                try:
+                    t1, t2, t3 = self._pyramid(torch.cat([FF.to_nhwc(x), FF.to_nhwc(ref)], dim=0))
+                finally:
+                    helpers.BN_GROUPS[0] = 1
+                (c1, r1), (c2, r2), (c3, r3) = FF.split_batch(t1, nb), FF.split_batch(t2, nb), FF.split_batch(t3, nb)
                 m = mask.contiguous().unsqueeze(-1)  # [N,H,W,1]
                 n = m.shape[0]
                 mask_3 = FF.resize_bilinear(m, r3.shape[1], r3.shape[2]).view(n, r3.shape[1], r3.shape[2])
@@ -101,6 +111,8 @@ class GradualStyleEncoder(Module):
                     c3 = self._blend(mask_3, r3, c3)
                     c2 = self._blend(mask_2, r2, c2)
                 c1 = self._blend(mask_1, r1, c1)
+            else:
+                c1, c2, c3 = self._pyramid(FF.to_nhwc(x))
             latents = [self.styles[j].nhwc(c3) for j in range(self.coarse_ind)]
             p2 = self._upsample_add(c3, run_conv(self.latlayer1, c2))
             latents += [self.styles[j].nhwc(p2) for j in range(self.coarse_ind, self.middle_ind)]
