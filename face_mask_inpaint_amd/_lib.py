@@ -89,6 +89,8 @@ SIGNATURES = {
     "fmi_maxpool_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_maxpool_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_argmax_channels_f32": [vp, vp, i64, i32, vp],
+    "fmi_scale_channels_add_f32": [vp, vp, vp, vp, i32, i64, i32, vp],
+    "fmi_instnorm_bwd_apply_add_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_copy_channels_f32": [vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "fmi_l2norm_rows_f32": [vp, vp, vp, i64, i32, f32, vp],
     "fmi_l2norm_rows_bwd_f32": [vp, vp, vp, vp, i64, i32, f32, vp],

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ red,
                                                            float* __restrict__ gx, int HW, int C4, int64_t total4,
-                                                           float slope) {
+                                                           float slope, const float* __restrict__ gadd) {
   const float inv_hw = 1.f / (float)HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     const int cg = (int)(i % C4);
@@ -245,6 +245,10 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restri
       const float m1 = (float)red[sc * 2] * inv_hw, m2 = (float)red[sc * 2 + 1] * inv_hw;
       o[e] = rstd * gamma[c] * (gp - m1 - xh * m2);
     }
+    if (gadd) {  // a second consumer of x (the identity shortcut of an IR block): its gradient joins here instead of in a separate add pass
+      const float4 a = reinterpret_cast<const float4*>(gadd)[i];
+      o[0] += a.x, o[1] += a.y, o[2] += a.z, o[3] += a.w;
+    }
     reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -260,9 +264,21 @@ __global__ void __launch_bounds__(256) in_param_grad_kernel(const double* __rest
   dbeta[c] += (float)s1;
   dgamma[c] += (float)s2;
 }
+static int in_bwd_apply_impl(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, const double* red,
+                             float* gx, float* dgamma, float* dbeta, int N, int HW, int C, float slope, const float* gadd, void* stream);
 extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
                                           const float* beta, const double* red, float* gx, float* dgamma, float* dbeta, int N,
                                           int HW, int C, float slope, void* stream) {
+  return in_bwd_apply_impl(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, nullptr, stream);
+}
+extern "C" int fmi_instnorm_bwd_apply_add_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                              const float* beta, const double* red, const float* gadd, float* gx, float* dgamma,
+                                              float* dbeta, int N, int HW, int C, float slope, void* stream) {
+  if (!gadd || ((uintptr_t)gadd & 15)) return FMI_ERR_BAD_ARG;
+  return in_bwd_apply_impl(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, gadd, stream);
+}
+static int in_bwd_apply_impl(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, const double* red,
+                             float* gx, float* dgamma, float* dbeta, int N, int HW, int C, float slope, const float* gadd, void* stream) {
   if (!x || !gy || !stats || !gamma || !beta || !red || !gx || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) ||
       ((uintptr_t)gy & 15) || ((uintptr_t)gx & 15))
     return FMI_ERR_BAD_ARG;
@@ -270,7 +286,7 @@ extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const
   hipStream_t st = (hipStream_t)stream;
   const int64_t total4 = (int64_t)N * HW * (C / 4);
   hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, st, x, gy, stats, gamma, beta, red, gx, HW,
-                     C / 4, total4, slope);
+                     C / 4, total4, slope, gadd);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(in_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, dgamma, dbeta, N, C);
   return fmi_launch_status();

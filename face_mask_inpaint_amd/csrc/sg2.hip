@@ -36,6 +36,27 @@ extern "C" int fmi_scale_channels_f32(const float* x, const float* s, float* y, 
   hipLaunchKernelGGL(scale_channels_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, s, y, P, C, total);
   return fmi_launch_status();
 }
+// y = x * s[n][c] + res: the SE gate and the residual add of a bottleneck_IR_SE block (helpers.py:64-72,116-118) in one pass
+__global__ void __launch_bounds__(256) scale_channels_add_vec_kernel(const float4* __restrict__ x, const float4* __restrict__ s,
+                                                                     const float4* __restrict__ res, float4* __restrict__ y, int64_t PC4,
+                                                                     int C4, int64_t total4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t n = i / PC4;
+    float4 v = x[i];
+    const float4 f = s[n * C4 + c4], r = res[i];
+    v.x = v.x * f.x + r.x, v.y = v.y * f.y + r.y, v.z = v.z * f.z + r.z, v.w = v.w * f.w + r.w;
+    y[i] = v;
+  }
+}
+extern "C" int fmi_scale_channels_add_f32(const float* x, const float* s, const float* res, float* y, int N, int64_t P, int C, void* stream) {
+  if (!x || !s || !res || !y || N <= 0 || P <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 != 0 || ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)s) | ((uintptr_t)res)) & 15) != 0) return FMI_ERR_UNSUPPORTED;
+  const int64_t total4 = (int64_t)N * P * (C / 4);
+  hipLaunchKernelGGL(scale_channels_add_vec_kernel, dim3(fmi_bw_grid(total4, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (const float4*)s, (const float4*)res, (float4*)y, P * (C / 4), C / 4, total4);
+  return fmi_launch_status();
+}
 // gs[n][c] = sum_p g[n][p][c] * x[n][p][c].  With a partials workspace (ws_floats >= N*C) every row block stores its sums as one row
 // and a second launch adds the rows (gs WRITTEN); without one the blocks add onto the caller-zeroed gs with fp32 atomics, which
 // serialise per address (52 us per launch on the SE gates of the pSp encoder).

@@ -1435,6 +1435,42 @@ def scale_channels(x, s):
     return _ScaleChannels.apply(x, s.contiguous())
 
 
+class _ScaleChannelsAdd(torch.autograd.Function):
+    """y[n,p,c] = x[n,p,c] * s[n,c] + res[n,p,c] (fp32): the SE gate and the residual add of an IR-SE block in one pass"""
+
+    @staticmethod
+    def forward(ctx, x, s, res):
+        _chk(x, s, res)
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        y = torch.empty_like(x)
+        _L().scale_channels_add_f32(_p(x), _p(s), _p(res), _p(y), n, p, c, _st())
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        gx = gs = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _L().scale_channels_f32(_p(g), _p(s), _p(gx), n, p, c, _st())
+        if ctx.needs_input_grad[1]:
+            gs = torch.empty_like(s)
+            ws = _parts_ws(x.device, max(2048, n) * c)
+            _L().scale_channels_gs_f32(_p(g), _p(x), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
+        return gx, gs, (g if ctx.needs_input_grad[2] else None)
+
+
+def scale_channels_add(x, s, res):
+    if x.dtype != torch.float32 or x.shape[-1] % 4 or x.shape != res.shape:
+        return add(scale_channels(x, s), res)
+    return _ScaleChannelsAdd.apply(x.contiguous(), s.contiguous(), res.contiguous())
+
+
 class _SqSumLast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1662,7 +1698,9 @@ class _BatchNormTrain(torch.autograd.Function):
     Returns (y, stats[G][C][2] = (mean, rstd), sums[G][C][2] = fp64 (sum, sum of squares))."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, groups=1):
+    def forward(ctx, x, gamma, beta, eps, groups=1, passthrough=False):
+        """passthrough: x itself is returned as a fourth output for x's OTHER consumer (the identity shortcut of an IR block); its
+        gradient then arrives here and joins gx inside the backward kernel instead of in a separate accumulation pass"""
         _chk(x, gamma, beta)
         lib = _L()
         c = x.shape[-1]
@@ -1678,12 +1716,16 @@ class _BatchNormTrain(torch.autograd.Function):
         ctx.groups = groups
         ctx.mark_non_differentiable(stats, sums)
         ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output (one fill launch per BatchNorm and step)
+        if passthrough:
+            return y, stats, sums, x.view_as(x)
         return y, stats, sums
 
     @staticmethod
-    def backward(ctx, g, _gstats, _gsums):
+    def backward(ctx, g, _gstats, _gsums, gpass=None):
         lib = _L()
         x, stats, gamma, beta = ctx.saved_tensors
+        if g is None:  # only the pass-through branch carried a gradient
+            return gpass, None, None, None, None, None
         c = x.shape[-1]
         groups = ctx.groups
         rows = x.numel() // c // groups
@@ -1692,9 +1734,13 @@ class _BatchNormTrain(torch.autograd.Function):
         lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), groups, rows, c, 1.0,
                                     C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
-        lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
-                                   groups, rows, c, 1.0, _st())
-        return gx, dg, db, None, None
+        if gpass is not None:
+            lib.instnorm_bwd_apply_add_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gpass.contiguous()),
+                                           _p(gx), _p(dg), _p(db), groups, rows, c, 1.0, _st())
+        else:
+            lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
+                                       groups, rows, c, 1.0, _st())
+        return gx, dg, db, None, None, None
 
 
 def batch_norm_running_update(stats, running_mean, running_var, num_batches_tracked, count, eps, momentum, sums=None):
@@ -1709,8 +1755,8 @@ def batch_norm_running_update(stats, running_mean, running_var, num_batches_trac
                                       _p(running_var), nbt, running_mean.numel(), int(count), float(eps), float(momentum), _st())
 
 
-def batch_norm_train(x, gamma, beta, eps=1e-5, groups=1):
-    return _BatchNormTrain.apply(x, gamma, beta, float(eps), int(groups))
+def batch_norm_train(x, gamma, beta, eps=1e-5, groups=1, passthrough=False):
+    return _BatchNormTrain.apply(x, gamma, beta, float(eps), int(groups), bool(passthrough))
 
 
 class _SplitBatch(torch.autograd.Function):

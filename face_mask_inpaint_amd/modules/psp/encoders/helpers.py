@@ -40,11 +40,17 @@ def get_blocks(num_layers):
 BN_GROUPS = [1]
 
 
-def batch_norm(bn: BatchNorm2d, x):
-    """nn.BatchNorm2d forward on NHWC with torch's training / eval semantics"""
+def batch_norm(bn: BatchNorm2d, x, passthrough=False):
+    """nn.BatchNorm2d forward on NHWC with torch's training / eval semantics.  ``passthrough``: returns (y, x') where x' is x for its
+    other consumer; in training mode that consumer's gradient is added inside the BatchNorm backward kernel (one pass fewer)"""
     if bn.training or not bn.track_running_stats:
         groups = BN_GROUPS[0]
-        y, stats, sums = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps, groups)
+        if passthrough:
+            y, stats, sums, xp = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps, groups, True)
+        else:
+            y, stats, sums = FF.batch_norm_train(x, bn.weight, bn.bias, bn.eps, groups)
+            xp = None
+        y = (y, xp) if passthrough else y
         if bn.training and bn.track_running_stats:
             cnt = x.numel() // x.shape[-1] // groups
             for g in range(groups):  # the running statistics see the parts one after the other, as the reference's separate calls do
@@ -68,7 +74,8 @@ def batch_norm(bn: BatchNorm2d, x):
     with torch.enable_grad() if want else torch.no_grad():
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
-    return FF.channel_affine(x, scale, shift)
+    y = FF.channel_affine(x, scale, shift)
+    return (y, x) if passthrough else y
 
 
 class SEModule(Module):
@@ -80,13 +87,16 @@ class SEModule(Module):
         self.fc2 = Conv2d(channels // reduction, channels, kernel_size=1, padding=0, bias=False)
         self.sigmoid = Sigmoid()
 
+    def gate(self, x):
+        """the [N, C] channel gates sigmoid(fc2(relu(fc1(avgpool(x)))))"""
+        n, h, w, c = x.shape
+        s = FF.avg_pool(x, h) if h == w else FF.adaptive_avg_pool(x, 1, 1)  # AdaptiveAvgPool2d(1) -> [N,1,1,C]
+        s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
+        return FF.sigmoid(run_conv(self.fc2, s)).view(n, c)
+
     def nhwc(self, x):
         with weight_scope(self):
-            n, h, w, c = x.shape
-            s = FF.avg_pool(x, h) if h == w else FF.adaptive_avg_pool(x, 1, 1)  # AdaptiveAvgPool2d(1) -> [N,1,1,C]
-            s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
-            s = FF.sigmoid(run_conv(self.fc2, s))
-            return FF.scale_channels(x, s.view(n, c))
+            return FF.scale_channels(x, self.gate(x))
 
     def forward(self, x):
         return FF.to_nchw(self.nhwc(FF.to_nhwc(x)))
@@ -95,17 +105,20 @@ class SEModule(Module):
 class _Bottleneck(Module):
     def nhwc(self, x):
         with weight_scope(self):
-            if isinstance(self.shortcut_layer, MaxPool2d):
-                sc = FF.subsample(x, self._stride)
+            if isinstance(self.shortcut_layer, MaxPool2d) and self._stride == 1:
+                # identity shortcut: x has two consumers (BatchNorm and the final add); the add's gradient re-enters through the
+                # BatchNorm backward kernel instead of an accumulation pass of its own
+                r, sc = batch_norm(self.res_layer[0], x, passthrough=True)
             else:
-                sc = batch_norm(self.shortcut_layer[1], run_conv(self.shortcut_layer[0], x))
-            r = batch_norm(self.res_layer[0], x)
+                sc = FF.subsample(x, self._stride) if isinstance(self.shortcut_layer, MaxPool2d) else \
+                    batch_norm(self.shortcut_layer[1], run_conv(self.shortcut_layer[0], x))
+                r = batch_norm(self.res_layer[0], x)
             r = run_conv(self.res_layer[1], r)
             r = FF.prelu(r, self.res_layer[2].weight)
             r = run_conv(self.res_layer[3], r)
             r = batch_norm(self.res_layer[4], r)
-            if len(self.res_layer) > 5:
-                r = self.res_layer[5].nhwc(r)
+            if len(self.res_layer) > 5:  # SE gate and residual add in one pass
+                return FF.scale_channels_add(r, self.res_layer[5].gate(r), sc)
             return FF.add(r, sc)
 
     def forward(self, x):

@@ -279,6 +279,13 @@ int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const float* o_r
 /* k x k mean pooling, stride k (nn.AvgPool2d(2,2) base_function.py:233; AdaptiveAvgPool2d 1024->256 model.py:79) */
 int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
 int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream);
+/* y = x * s[n][c] + res: SE gate and residual add of a bottleneck_IR_SE block (helpers.py:64-72,116-118) in one pass (C % 4 == 0) */
+int fmi_scale_channels_add_f32(const float* x, const float* s, const float* res, float* y, int N, int64_t P, int C, void* stream);
+/* fmi_instnorm_bwd_apply_f32 with gx += gadd: the gradient of a second consumer of x (the identity shortcut of an IR block) joins in the
+ * same pass */
+int fmi_instnorm_bwd_apply_add_f32(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta,
+                                   const double* red, const float* gadd, float* gx, float* dgamma, float* dbeta, int N, int HW, int C,
+                                   float slope, void* stream);
 /* y[r][:] = x[r][:] / (||x[r]|| + eps), inv_norm[r] = 1 / (||x[r]|| + eps): LPIPS' normalize_activation over the channels of a
  * pixel (criteria/lpips/utils.py:6-8, eps 1e-10) and ArcFace's l2_norm of an embedding (encoders/helpers.py:15-18, eps 0) */
 int fmi_l2norm_rows_f32(const float* x, float* y, float* inv_norm, int64_t rows, int C, float eps, void* stream);
