@@ -142,7 +142,7 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
   if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
   if (d->pad_mode != 0) return FMI_ERR_UNSUPPORTED;  // reflect: run on the padded extent, then fmi_reflect_pad_fold_f32
   if (batch_w > 1 && batch_w != d->N) return FMI_ERR_BAD_ARG;
-  if (mask && (bias || residual)) return FMI_ERR_UNSUPPORTED;  // the mask applies to the bare adjoint
+  if (mask && bias) return FMI_ERR_UNSUPPORTED;  // the mask applies to the bare adjoint; a residual is added AFTER it (ConvEp: v * mask + res)
 #ifndef FMI_HOST_EMU
   if (batch_w == 1 && !bias && !residual && !mask && fmi_conv2d_thin_supported(d) && aligned16(dx))
     return fmi_conv2d_thin_dgrad_f32(d, dy, wt, dx, stream);
@@ -256,6 +256,12 @@ extern "C" int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* 
                                            float* dx, void* stream) {
   if (!mask) return FMI_ERR_BAD_ARG;
   return dgrad_impl(d, dy, wt, nullptr, nullptr, mask, mask_slope, dx, 1, 0, stream);
+}
+
+extern "C" int fmi_conv2d_dgrad_masked_add_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope,
+                                               const float* gadd, float* dx, void* stream) {
+  if (!mask || !gadd) return FMI_ERR_BAD_ARG;
+  return dgrad_impl(d, dy, wt, nullptr, gadd, mask, mask_slope, dx, 1, 0, stream);
 }
 
 extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,

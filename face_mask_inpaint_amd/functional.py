@@ -246,13 +246,14 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, W) + bias + residual); x [N,H,W,C], wf [taps][C][K]."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False, dil=1):
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False, dil=1, passthrough=False):
         """in_act: None, ("apply", slope): the convolution reads lrelu(x, slope) (computed here, and only IT is kept for the backward),
         ("mask", slope): x already is the output of such an activation; either way the input gradient is multiplied by act'(x) in the
         adjoint's epilogue.  skip_act_bwd: this convolution's own fused activation (act) is differentiated by its single consumer (a
         following convolution with in_act = ("mask", .)), not here."""
         _chk(x, wf, bias, residual)
         lib = _L()
+        x_in = x
         if in_act is not None and in_act[0] == "apply":
             x = eltwise(EW_LRELU, x, None, in_act[1])
         n, h, w, c = x.shape
@@ -266,12 +267,16 @@ class _Conv2d(torch.autograd.Function):
         ctx.dil = dil
         ctx.in_slope = None if in_act is None else float(in_act[1])
         ctx.skip_act_bwd = bool(skip_act_bwd)
+        if passthrough:  # the input handed on to its OTHER consumer: that consumer's gradient comes back into this backward
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gpass=None):
         lib = _L()
         x, wf, y = ctx.saved_tensors
+        if gy is None:
+            return (gpass,) + (None,) * 15
         kh, kw, stride, pad, pad_mode, act = ctx.cfg
         gy = gy.contiguous()
         if act and not ctx.skip_act_bwd:
@@ -299,13 +304,23 @@ class _Conv2d(torch.autograd.Function):
                 d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
-                    if ctx.in_slope is not None:  # act'(x) folded into the adjoint's epilogue
+                    if ctx.in_slope is not None and gpass is not None:  # act'(x) in the epilogue, then + the other consumer's gradient
+                        lib.conv2d_dgrad_masked_add_f32(C.byref(d), _p(gy), _p(ctx.wt), _p(x), ctx.in_slope, _p(gpass.contiguous()), _p(gx), _st())
+                        masked, gpass = True, None
+                    elif ctx.in_slope is not None:  # act'(x) folded into the adjoint's epilogue
                         lib.conv2d_dgrad_masked_f32(C.byref(d), _p(gy), _p(ctx.wt), _p(x), ctx.in_slope, _p(gx), _st())
                         masked = True
+                    elif gpass is not None:
+                        lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, _p(gpass.contiguous()), _p(gx), 1, 0, _st())
+                        gpass = None
                     else:
                         lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gx), 1, 0, _st())
             if ctx.in_slope is not None and not masked:
                 gx = eltwise(EW_LRELU_BWD, gx, x, ctx.in_slope)
+            if gpass is not None:  # paths without a fused epilogue (thin / reflect)
+                gx = eltwise(EW_ADD, gx, gpass.contiguous())
+        elif gpass is not None:
+            gx = gpass
         if ctx.needs_input_grad[1]:
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
             gwf = _zeros_like(wf)
@@ -320,7 +335,7 @@ class _Conv2d(torch.autograd.Function):
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
-        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _ThinConvLReLU(torch.autograd.Function):
@@ -379,12 +394,14 @@ def lrelu_conv2d(x, pw: PackedWeight, bias=None, slope=0.1, pad=1, pad_mode=0, a
     return conv2d(leaky_relu(x, slope), pw, bias, None, 1, pad, pad_mode, act)
 
 
-def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, in_act=None, skip_act_bwd=False, dilation=1):
+def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_mode=0, act=ACT_NONE, in_act=None, skip_act_bwd=False, dilation=1,
+           passthrough=False):
+    """passthrough=True: returns (y, x') with x' = x for x's other consumer (see _Conv2d)"""
     if x.dtype == BF16:
         if bias is not None or residual is not None or pad_mode or act or in_act is not None or dilation != 1:
             raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding / dilation form")
         return _Conv2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad)
-    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd, int(dilation))
+    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd, int(dilation), bool(passthrough))
 
 
 # ---- bf16 activations (StyleGAN2 decoder of configs C3 / C5): fp32 master weights, bf16 copies packed per call ----
@@ -814,7 +831,7 @@ def _norm_ws(device, n, c):
 
 class _InstNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, slope):
+    def forward(ctx, x, gamma, beta, eps, slope, passthrough=False):
         _chk(x, gamma, beta)
         lib = _L()
         n, h, w, c = x.shape
@@ -825,12 +842,16 @@ class _InstNormAct(torch.autograd.Function):
         lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), n, h * w, c, slope, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.slope = slope
+        if passthrough:  # x for its other consumer (the bypass ConvTranspose2d of a ResBlockDecoder): its gradient re-enters below
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gpass=None):
         lib = _L()
         x, stats, gamma, beta = ctx.saved_tensors
+        if g is None:
+            return gpass, None, None, None, None, None
         n, h, w, c = x.shape
         g = g.contiguous()
         red, ws = _norm_ws(x.device, n, c)
@@ -839,14 +860,18 @@ class _InstNormAct(torch.autograd.Function):
         gx = torch.empty_like(x)
         dg = _zeros_like(gamma)
         db = _zeros_like(beta)
-        lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
-                                   n, h * w, c, ctx.slope, _st())
-        return gx, dg, db, None, None
+        if gpass is not None:
+            lib.instnorm_bwd_apply_add_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gpass.contiguous()),
+                                           _p(gx), _p(dg), _p(db), n, h * w, c, ctx.slope, _st())
+        else:
+            lib.instnorm_bwd_apply_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gx), _p(dg), _p(db),
+                                       n, h * w, c, ctx.slope, _st())
+        return gx, dg, db, None, None, None
 
 
-def instance_norm_act(x, gamma, beta, eps=1e-5, slope=1.0):
-    """lrelu(InstanceNorm2d(affine)(x)); slope = 1 disables the activation."""
-    return _InstNormAct.apply(x, gamma, beta, eps, slope)
+def instance_norm_act(x, gamma, beta, eps=1e-5, slope=1.0, passthrough=False):
+    """lrelu(InstanceNorm2d(affine)(x)); slope = 1 disables the activation.  passthrough: returns (y, x') -- see _InstNormAct"""
+    return _InstNormAct.apply(x, gamma, beta, eps, slope, passthrough)
 
 
 class _MaskMul(torch.autograd.Function):

@@ -110,10 +110,10 @@ def _conv(m):
     return m.module if isinstance(m, SpectralNorm) else m
 
 
-def _norm_act(norm: nn.Module, x, slope):
+def _norm_act(norm: nn.Module, x, slope, passthrough=False):
     if not isinstance(norm, nn.InstanceNorm2d) or not norm.affine or norm.track_running_stats:
         raise NotImplementedError("only InstanceNorm2d(affine=True) is on the hot path")
-    return FF.instance_norm_act(x, norm.weight, norm.bias, norm.eps, slope)
+    return FF.instance_norm_act(x, norm.weight, norm.bias, norm.eps, slope, passthrough)
 
 
 class _NhwcBlock(nn.Module):
@@ -150,14 +150,17 @@ class ResBlock(_NhwcBlock):
 
     def nhwc(self, x):
         with weight_scope(self):
-            s = run_conv(_conv(self.bypass), x)
+            # x has two consumers (the main path and the 1x1 bypass): the bypass reads the pass-through copy the main path's first op
+            # hands on, so its gradient re-enters that op's backward kernel instead of an accumulation pass of its own
             if self._norms is None:
                 # LeakyReLU -> conv pairs: the activation is applied on the way in and differentiated in the adjoint's epilogue
                 act_in = ("apply", self._slope)
-                h = run_conv(_conv(self.conv1), x, in_act=act_in)
+                h, xp = run_conv(_conv(self.conv1), x, in_act=act_in, passthrough=True)
+                s = run_conv(_conv(self.bypass), xp)
                 out = run_conv(_conv(self.conv2), h, residual=s, in_act=act_in)  # model(x) + shortcut(x), fused in the epilogue
             else:
-                h = _norm_act(self.model[0], x, self._slope)
+                h, xp = _norm_act(self.model[0], x, self._slope, passthrough=True)
+                s = run_conv(_conv(self.bypass), xp)
                 h = run_conv(_conv(self.conv1), h)
                 h = _norm_act(self.model[3], h, self._slope)
                 out = run_conv(_conv(self.conv2), h, residual=s)  # model(x) + shortcut(x), fused in the epilogue
@@ -180,8 +183,8 @@ class ResBlockEncoderOptimized(_NhwcBlock):
 
     def nhwc(self, x):
         with weight_scope(self):
-            s = run_conv(_conv(self.bypass), FF.avg_pool(x, 2))
-            h = run_conv(_conv(self.conv1), x)
+            h, xp = run_conv(_conv(self.conv1), x, passthrough=True)
+            s = run_conv(_conv(self.bypass), FF.avg_pool(xp, 2))
             h = run_conv(_conv(self.conv2), h, in_act=("apply", self._slope))
             return FF.add(FF.avg_pool(h, 2), s)
 
@@ -205,12 +208,13 @@ class ResBlockDecoder(_NhwcBlock):
 
     def nhwc(self, x):
         with weight_scope(self):
-            s = run_conv(_conv(self.bypass), x)
             if self._norms is None:
-                h = run_conv(_conv(self.conv1), x, in_act=("apply", self._slope))
+                h, xp = run_conv(_conv(self.conv1), x, in_act=("apply", self._slope), passthrough=True)
+                s = run_conv(_conv(self.bypass), xp)
                 h = FF.leaky_relu(h, self._slope)
             else:
-                h = _norm_act(self.model[0], x, self._slope)
+                h, xp = _norm_act(self.model[0], x, self._slope, passthrough=True)  # the bypass ConvTranspose2d's gradient joins in the IN backward
+                s = run_conv(_conv(self.bypass), xp)
                 h = run_conv(_conv(self.conv1), h)
                 h = _norm_act(self.model[3], h, self._slope)
             return run_conv(_conv(self.conv2), h, residual=s)

@@ -53,9 +53,11 @@ class SpectralNorm(nn.Module):
             return run_conv(self.module, x_nhwc, residual=residual, act=act, pad_mode=pad_mode, pad=pad)
 
 
-def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0, pad=None, in_act=None, skip_act_bwd=False):
+def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0, pad=None, in_act=None, skip_act_bwd=False, passthrough=False):
     """Run a (prepared) nn.Conv2d / nn.ConvTranspose2d parameter holder on an NHWC tensor.  ``in_act`` = ("apply", slope): the
-    convolution reads lrelu(x, slope); ("mask", slope): x already is that activation's output -- see functional._Conv2d."""
+    convolution reads lrelu(x, slope); ("mask", slope): x already is that activation's output -- see functional._Conv2d.
+    ``passthrough`` (Conv2d only): returns (y, x') with x' = the input for its OTHER consumer, whose gradient then joins inside this
+    convolution's adjoint kernel instead of in a separate accumulation pass."""
     pw = packed(conv)
     if isinstance(conv, nn.ConvTranspose2d):
         if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1:
@@ -68,7 +70,7 @@ def run_conv(conv: nn.Module, x_nhwc, residual=None, act=FF.ACT_NONE, pad_mode=0
     if conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] or conv.groups != 1 or conv.dilation[0] != conv.dilation[1]:
         raise NotImplementedError("Conv2d geometry outside the hot path")
     p = conv.padding[0] if pad is None else pad
-    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act, in_act, skip_act_bwd, conv.dilation[0])
+    return FF.conv2d(x_nhwc, pw, conv.bias, residual, conv.stride[0], p, pad_mode, act, in_act, skip_act_bwd, conv.dilation[0], passthrough)
 
 
 class GANLoss(nn.Module):

@@ -38,6 +38,7 @@ def get_blocks(num_layers):
 # > 1 while a module runs a batch made of that many parts that are SEPARATE forward calls in the reference (GradualStyleEncoder runs
 # its body on the source and then on the reference image): training-mode BatchNorm then normalises and updates per part, in order
 BN_GROUPS = [1]
+_FUSE = __import__("os").environ.get("FMI_IRSE_FUSE_OFF") is None  # debug: A/B of the block-level fusions below
 
 
 def batch_norm(bn: BatchNorm2d, x, passthrough=False):
@@ -105,7 +106,7 @@ class SEModule(Module):
 class _Bottleneck(Module):
     def nhwc(self, x):
         with weight_scope(self):
-            if isinstance(self.shortcut_layer, MaxPool2d) and self._stride == 1:
+            if _FUSE and isinstance(self.shortcut_layer, MaxPool2d) and self._stride == 1:
                 # identity shortcut: x has two consumers (BatchNorm and the final add); the add's gradient re-enters through the
                 # BatchNorm backward kernel instead of an accumulation pass of its own
                 r, sc = batch_norm(self.res_layer[0], x, passthrough=True)
@@ -117,8 +118,10 @@ class _Bottleneck(Module):
             r = FF.prelu(r, self.res_layer[2].weight)
             r = run_conv(self.res_layer[3], r)
             r = batch_norm(self.res_layer[4], r)
-            if len(self.res_layer) > 5:  # SE gate and residual add in one pass
+            if len(self.res_layer) > 5 and _FUSE:  # SE gate and residual add in one pass
                 return FF.scale_channels_add(r, self.res_layer[5].gate(r), sc)
+            if len(self.res_layer) > 5:
+                r = self.res_layer[5].nhwc(r)
             return FF.add(r, sc)
 
     def forward(self, x):

@@ -93,6 +93,10 @@ int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* w
  * Zero padding, shared weights, no bias / residual. */
 int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope, float* dx,
                                 void* stream);
+/* the same with dx = conv_adjoint(dy, wt) * act'(x) + gadd: x's second consumer in a ResBlock (the 1x1 bypass convolution,
+ * base_function.py:242-268) hands its gradient in here, so no separate accumulation pass runs */
+int fmi_conv2d_dgrad_masked_add_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope,
+                                    const float* gadd, float* dx, void* stream);
 /* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf.
  * dbias (may be NULL; needs kh*kw*C % 4 == 0 and batch_w == 1): dbias[k] += sum over pixels dy[p][k], computed by the same
  * GEMM as one extra row of ones -- no separate pass over dy; caller zeroes it. */
