@@ -90,6 +90,17 @@ SIGNATURES = {
     "fmi_maxpool_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_maxpool_bwd_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_argmax_channels_f32": [vp, vp, i64, i32, vp],
+    "fmi_instnorm_stats_bf16": [vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
+    "fmi_instnorm_apply_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_instnorm_bwd_reduce_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
+    "fmi_instnorm_bwd_apply_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "fmi_prelu_bf16": [vp, vp, vp, i64, i32, vp],
+    "fmi_prelu_bwd_bf16": [vp, vp, vp, vp, vp, vp, i64, i64, i32, vp],
+    "fmi_scale_channels_add_bf16": [vp, vp, vp, vp, i32, i64, i32, vp],
+    "fmi_add_bf16": [vp, vp, vp, i64, vp],
+    "fmi_global_avgpool_bf16": [vp, vp, vp, i64, i32, i64, i32, vp],
+    "fmi_add_bcast_bf16": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_subsample_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_scale_channels_add_f32": [vp, vp, vp, vp, i32, i64, i32, vp],
     "fmi_instnorm_bwd_apply_add_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "fmi_copy_channels_f32": [vp, vp, i64, i32, i32, i32, i32, i32, vp],

@@ -6,6 +6,23 @@
 // Layout of a workgroup: 256 threads = PL pixel lanes x CG channel groups (4 channels each), CG = C/4.
 #include "common.h"
 
+// Element types: float, or bf16 held as uint16_t (the mixed-precision IR-SE50 body of the pSp encoder: bf16 activations, fp32
+// statistics / parameters / arithmetic).  Four channels per thread either way: a 16-byte or an 8-byte access.
+__device__ __forceinline__ float nb_bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t nb_f2bf(float f) {  // round to nearest even
+  const uint32_t u = __float_as_uint(f);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float4 nld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 nld4(const uint16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(nb_bf2f(v.x & 0xffffu), nb_bf2f(v.x >> 16), nb_bf2f(v.y & 0xffffu), nb_bf2f(v.y >> 16));
+}
+__device__ __forceinline__ void nst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void nst4(uint16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(nb_f2bf(v.x) | (nb_f2bf(v.y) << 16), nb_f2bf(v.z) | (nb_f2bf(v.w) << 16));
+}
+
 // pixels per workgroup chunk: at least 64, grown until at most `cap` workgroups exist.  With fp64 atomics (no workspace) every
 // workgroup adds 2 C values onto the same 2 C addresses, and those serialise: more workgroups were SLOWER there (cap 2048 from 512-row
 // chunks).  With a partials workspace each workgroup stores its own row and a second launch adds the rows, so the chunk can shrink
@@ -43,8 +60,8 @@ __global__ void __launch_bounds__(1024) sum_parts_f64_kernel(const double* __res
 }
 
 // sums[n][c][0..1] += (sum f0, sum f1) where (f0,f1) = fn(x, g) per element
-template <int MODE>  // 0: (x, x*x)   1: backward reductions (g', g'*xhat)
-__global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+template <int MODE, typename T>  // 0: (x, x*x)   1: backward reductions (g', g'*xhat)
+__global__ void __launch_bounds__(256) in_reduce_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, double* __restrict__ sums, int HW,
                                                         int C, float slope, int rpb, int to_parts) {
@@ -95,15 +112,15 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int64_t o = ((int64_t)n * HW + p + u * PL) * C + cg * 4;
-        v[u] = *reinterpret_cast<const float4*>(x + o);
-        g4[u] = MODE == 1 ? *reinterpret_cast<const float4*>(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = nld4(x + o);
+        g4[u] = MODE == 1 ? nld4(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) body(v[u], g4[u]);
     }
     for (; p < p1; p += PL) {
       const int64_t o = ((int64_t)n * HW + p) * C + cg * 4;
-      body(*reinterpret_cast<const float4*>(x + o), MODE == 1 ? *reinterpret_cast<const float4*>(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f));
+      body(nld4(x + o), MODE == 1 ? nld4(gy + o) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
 #pragma unroll
@@ -137,20 +154,20 @@ __global__ void __launch_bounds__(256) in_reduce_kernel(const float* __restrict_
 }
 // launches the reduction; with a workspace of ws_doubles >= N * C * 2 doubles the sums are WRITTEN (partials + one adding launch),
 // without one they are accumulated onto the caller-zeroed buffer by fp64 atomics
-template <int MODE>
-static void launch_in_reduce(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, double* sums,
+template <int MODE, typename T>
+static void launch_in_reduce(const T* x, const T* gy, const float* stats, const float* gamma, const float* beta, double* sums,
                              int N, int HW, int C, float slope, double* ws, int64_t ws_doubles, hipStream_t st) {
   if (ws && ws_doubles >= (int64_t)N * C * 2 && (((uintptr_t)ws) & 15) == 0) {
     int64_t cap = ws_doubles / ((int64_t)C * 2);
     if (cap > 1024) cap = 1024;
     const int rpb = rows_per_block(N, HW, cap, 64);
     const int blocks = (HW + rpb - 1) / rpb;
-    hipLaunchKernelGGL((in_reduce_kernel<MODE>), dim3(blocks, N), dim3(256), 0, st, x, gy, stats, gamma, beta, ws, HW, C, slope, rpb, 1);
+    hipLaunchKernelGGL((in_reduce_kernel<MODE, T>), dim3(blocks, N), dim3(256), 0, st, x, gy, stats, gamma, beta, ws, HW, C, slope, rpb, 1);
     hipLaunchKernelGGL(sum_parts_f64_kernel, dim3((C * 2 + 63) / 64, N), dim3(1024), 0, st, (const double*)ws, sums, blocks, C * 2);
     return;
   }
   const int rpb = rows_per_block(N, HW, 2048, 512);
-  hipLaunchKernelGGL((in_reduce_kernel<MODE>), dim3((HW + rpb - 1) / rpb, N), dim3(256), 0, st, x, gy, stats, gamma, beta, sums, HW, C, slope,
+  hipLaunchKernelGGL((in_reduce_kernel<MODE, T>), dim3((HW + rpb - 1) / rpb, N), dim3(256), 0, st, x, gy, stats, gamma, beta, sums, HW, C, slope,
                      rpb, 0);
 }
 
@@ -171,23 +188,32 @@ static int check_c(int C) {
   return FMI_OK;
 }
 
-extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws,
-                                      int64_t ws_doubles, void* stream) {
-  if (!x || !sums || !stats || N <= 0 || HW <= 0 || C <= 0 || ((uintptr_t)x & 15)) return FMI_ERR_BAD_ARG;
+template <typename T>
+static int stats_impl(const T* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws, int64_t ws_doubles, void* stream) {
+  if (!x || !sums || !stats || N <= 0 || HW <= 0 || C <= 0 || ((uintptr_t)x & (4 * sizeof(T) - 1))) return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  launch_in_reduce<0>(x, nullptr, nullptr, nullptr, nullptr, sums, N, HW, C, 1.f, ws, ws_doubles, st);
+  launch_in_reduce<0, T>(x, (const T*)nullptr, nullptr, nullptr, nullptr, sums, N, HW, C, 1.f, ws, ws_doubles, st);
   hipLaunchKernelGGL(in_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, (const double*)sums, stats, N * C, HW, eps);
   return fmi_launch_status();
 }
+extern "C" int fmi_instnorm_stats_f32(const float* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws,
+                                      int64_t ws_doubles, void* stream) {
+  return stats_impl(x, sums, stats, N, HW, C, eps, ws, ws_doubles, stream);
+}
+extern "C" int fmi_instnorm_stats_bf16(const uint16_t* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws,
+                                       int64_t ws_doubles, void* stream) {
+  return stats_impl(x, sums, stats, N, HW, C, eps, ws, ws_doubles, stream);
+}
 
-__global__ void __launch_bounds__(256) in_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+template <typename T>
+__global__ void __launch_bounds__(256) in_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ y, int HW, int C4, int64_t total4, float slope) {
+                                                       T* __restrict__ y, int HW, int C4, int64_t total4, float slope) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     const int cg = (int)(i % C4);
     const int n = (int)(i / ((int64_t)HW * C4));
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = nld4(x + i * 4);
     const float xv[4] = {v.x, v.y, v.z, v.w};
     float o[4];
 #pragma unroll
@@ -197,41 +223,61 @@ __global__ void __launch_bounds__(256) in_apply_kernel(const float* __restrict__
       const float pre = (xv[e] - s[0]) * s[1] * gamma[c] + beta[c];
       o[e] = pre > 0.f ? pre : pre * slope;
     }
-    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    nst4(y + i * 4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
-extern "C" int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
-                                      int N, int HW, int C, float slope, void* stream) {
-  if (!x || !stats || !gamma || !beta || !y || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return FMI_ERR_BAD_ARG;
+template <typename T>
+static int apply_impl(const T* x, const float* stats, const float* gamma, const float* beta, T* y, int N, int HW, int C, float slope, void* stream) {
+  const uintptr_t al = 4 * sizeof(T) - 1;
+  if (!x || !stats || !gamma || !beta || !y || N <= 0 || HW <= 0 || ((uintptr_t)x & al) || ((uintptr_t)y & al)) return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
   const int64_t total4 = (int64_t)N * HW * (C / 4);
-  hipLaunchKernelGGL(in_apply_kernel, dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y,
+  hipLaunchKernelGGL((in_apply_kernel<T>), dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta, y,
                      HW, C / 4, total4, slope);
   return fmi_launch_status();
 }
+extern "C" int fmi_instnorm_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, float* y,
+                                      int N, int HW, int C, float slope, void* stream) {
+  return apply_impl(x, stats, gamma, beta, y, N, HW, C, slope, stream);
+}
+extern "C" int fmi_instnorm_apply_bf16(const uint16_t* x, const float* stats, const float* gamma, const float* beta, uint16_t* y,
+                                       int N, int HW, int C, float slope, void* stream) {
+  return apply_impl(x, stats, gamma, beta, y, N, HW, C, slope, stream);
+}
 
+template <typename T>
+static int bwd_reduce_impl(const T* x, const T* gy, const float* stats, const float* gamma, const float* beta, double* red, int N, int HW, int C,
+                           float slope, double* ws, int64_t ws_doubles, void* stream) {
+  const uintptr_t al = 4 * sizeof(T) - 1;
+  if (!x || !gy || !stats || !gamma || !beta || !red || N <= 0 || HW <= 0 || ((uintptr_t)x & al) || ((uintptr_t)gy & al)) return FMI_ERR_BAD_ARG;
+  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
+  launch_in_reduce<1, T>(x, gy, stats, gamma, beta, red, N, HW, C, slope, ws, ws_doubles, (hipStream_t)stream);
+  return fmi_launch_status();
+}
 extern "C" int fmi_instnorm_bwd_reduce_f32(const float* x, const float* gy, const float* stats, const float* gamma,
                                            const float* beta, double* red, int N, int HW, int C, float slope, double* ws,
                                            int64_t ws_doubles, void* stream) {
-  if (!x || !gy || !stats || !gamma || !beta || !red || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)gy & 15))
-    return FMI_ERR_BAD_ARG;
-  if (check_c(C)) return FMI_ERR_UNSUPPORTED;
-  launch_in_reduce<1>(x, gy, stats, gamma, beta, red, N, HW, C, slope, ws, ws_doubles, (hipStream_t)stream);
-  return fmi_launch_status();
+  return bwd_reduce_impl(x, gy, stats, gamma, beta, red, N, HW, C, slope, ws, ws_doubles, stream);
+}
+extern "C" int fmi_instnorm_bwd_reduce_bf16(const uint16_t* x, const uint16_t* gy, const float* stats, const float* gamma,
+                                            const float* beta, double* red, int N, int HW, int C, float slope, double* ws,
+                                            int64_t ws_doubles, void* stream) {
+  return bwd_reduce_impl(x, gy, stats, gamma, beta, red, N, HW, C, slope, ws, ws_doubles, stream);
 }
 
 // gx = rstd*gamma*(g' - mean(g') - xhat*mean(g'*xhat))
-__global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+template <typename T>
+__global__ void __launch_bounds__(256) in_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ red,
-                                                           float* __restrict__ gx, int HW, int C4, int64_t total4,
-                                                           float slope, const float* __restrict__ gadd) {
+                                                           T* __restrict__ gx, int HW, int C4, int64_t total4,
+                                                           float slope, const T* __restrict__ gadd) {
   const float inv_hw = 1.f / (float)HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     const int cg = (int)(i % C4);
     const int n = (int)(i / ((int64_t)HW * C4));
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+    const float4 v = nld4(x + i * 4);
+    const float4 g4 = nld4(gy + i * 4);
     const float xv[4] = {v.x, v.y, v.z, v.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
     float o[4];
 #pragma unroll
@@ -246,10 +292,10 @@ __global__ void __launch_bounds__(256) in_bwd_apply_kernel(const float* __restri
       o[e] = rstd * gamma[c] * (gp - m1 - xh * m2);
     }
     if (gadd) {  // a second consumer of x (the identity shortcut of an IR block): its gradient joins here instead of in a separate add pass
-      const float4 a = reinterpret_cast<const float4*>(gadd)[i];
+      const float4 a = nld4(gadd + i * 4);
       o[0] += a.x, o[1] += a.y, o[2] += a.z, o[3] += a.w;
     }
-    reinterpret_cast<float4*>(gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    nst4(gx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 __global__ void __launch_bounds__(256) in_param_grad_kernel(const double* __restrict__ red, float* __restrict__ dgamma,
@@ -264,32 +310,38 @@ __global__ void __launch_bounds__(256) in_param_grad_kernel(const double* __rest
   dbeta[c] += (float)s1;
   dgamma[c] += (float)s2;
 }
-static int in_bwd_apply_impl(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, const double* red,
-                             float* gx, float* dgamma, float* dbeta, int N, int HW, int C, float slope, const float* gadd, void* stream);
-extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
-                                          const float* beta, const double* red, float* gx, float* dgamma, float* dbeta, int N,
-                                          int HW, int C, float slope, void* stream) {
-  return in_bwd_apply_impl(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, nullptr, stream);
-}
-extern "C" int fmi_instnorm_bwd_apply_add_f32(const float* x, const float* gy, const float* stats, const float* gamma,
-                                              const float* beta, const double* red, const float* gadd, float* gx, float* dgamma,
-                                              float* dbeta, int N, int HW, int C, float slope, void* stream) {
-  if (!gadd || ((uintptr_t)gadd & 15)) return FMI_ERR_BAD_ARG;
-  return in_bwd_apply_impl(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, gadd, stream);
-}
-static int in_bwd_apply_impl(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta, const double* red,
-                             float* gx, float* dgamma, float* dbeta, int N, int HW, int C, float slope, const float* gadd, void* stream) {
-  if (!x || !gy || !stats || !gamma || !beta || !red || !gx || N <= 0 || HW <= 0 || ((uintptr_t)x & 15) ||
-      ((uintptr_t)gy & 15) || ((uintptr_t)gx & 15))
+template <typename T>
+static int in_bwd_apply_impl(const T* x, const T* gy, const float* stats, const float* gamma, const float* beta, const double* red,
+                             T* gx, float* dgamma, float* dbeta, int N, int HW, int C, float slope, const T* gadd, void* stream) {
+  const uintptr_t al = 4 * sizeof(T) - 1;
+  if (!x || !gy || !stats || !gamma || !beta || !red || !gx || N <= 0 || HW <= 0 || ((uintptr_t)x & al) || ((uintptr_t)gy & al) ||
+      ((uintptr_t)gx & al) || ((uintptr_t)gadd & al))
     return FMI_ERR_BAD_ARG;
   if (check_c(C)) return FMI_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t total4 = (int64_t)N * HW * (C / 4);
-  hipLaunchKernelGGL(in_bwd_apply_kernel, dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, st, x, gy, stats, gamma, beta, red, gx, HW,
+  hipLaunchKernelGGL((in_bwd_apply_kernel<T>), dim3(fmi_bw_grid(total4, 256)), dim3(256), 0, st, x, gy, stats, gamma, beta, red, gx, HW,
                      C / 4, total4, slope, gadd);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(in_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, red, dgamma, dbeta, N, C);
   return fmi_launch_status();
+}
+extern "C" int fmi_instnorm_bwd_apply_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                          const float* beta, const double* red, float* gx, float* dgamma, float* dbeta, int N,
+                                          int HW, int C, float slope, void* stream) {
+  return in_bwd_apply_impl<float>(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, nullptr, stream);
+}
+extern "C" int fmi_instnorm_bwd_apply_add_f32(const float* x, const float* gy, const float* stats, const float* gamma,
+                                              const float* beta, const double* red, const float* gadd, float* gx, float* dgamma,
+                                              float* dbeta, int N, int HW, int C, float slope, void* stream) {
+  if (!gadd) return FMI_ERR_BAD_ARG;
+  return in_bwd_apply_impl<float>(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, gadd, stream);
+}
+// bf16 activations (gadd may be NULL)
+extern "C" int fmi_instnorm_bwd_apply_bf16(const uint16_t* x, const uint16_t* gy, const float* stats, const float* gamma, const float* beta,
+                                           const double* red, const uint16_t* gadd, uint16_t* gx, float* dgamma, float* dbeta, int N, int HW,
+                                           int C, float slope, void* stream) {
+  return in_bwd_apply_impl<uint16_t>(x, gy, stats, gamma, beta, red, gx, dgamma, dbeta, N, HW, C, slope, gadd, stream);
 }
 
 // nn.BatchNorm2d running-statistics bookkeeping (torch/nn/modules/batchnorm.py semantics: momentum average of the batch mean and of

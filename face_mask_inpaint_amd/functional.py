@@ -675,6 +675,11 @@ class _MulAdd(torch.autograd.Function):
 class _Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        if a.dtype == BF16:
+            _chk(a, b, dtype=BF16)
+            y = torch.empty_like(a)
+            _L().add_bf16(_p(a), _p(b), _p(y), a.numel(), _st())
+            return y
         return eltwise(EW_ADD, a, b)
 
     @staticmethod
@@ -1490,10 +1495,66 @@ class _ScaleChannelsAdd(torch.autograd.Function):
         return gx, gs, (g if ctx.needs_input_grad[2] else None)
 
 
+class _ScaleChannelsAddBF16(torch.autograd.Function):
+    """bf16 twin of _ScaleChannelsAdd (fp32 gates)"""
+
+    @staticmethod
+    def forward(ctx, x, s, res):
+        _chk(x, res, dtype=BF16)
+        _chk(s)
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        y = torch.empty_like(x)
+        _L().scale_channels_add_bf16(_p(x), _p(s), _p(res), _p(y), n, p, c, _st())
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = g.contiguous()
+        n, c = s.shape
+        p = x.numel() // (n * c)
+        gx = torch.empty_like(x)
+        _L().scale_channels_bf16(_p(g), _p(s), _p(gx), n, p, c, _st())
+        gs = torch.empty_like(s)
+        ws = _parts_ws(x.device, max(2048, n) * c)
+        _L().scale_channels_gs_bf16(_p(g), _p(x), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
+        return gx, gs, g
+
+
 def scale_channels_add(x, s, res):
+    if x.dtype == BF16 and x.shape == res.shape and x.shape[-1] % 8 == 0:
+        return _ScaleChannelsAddBF16.apply(x.contiguous(), s.contiguous(), res.contiguous())
     if x.dtype != torch.float32 or x.shape[-1] % 4 or x.shape != res.shape:
         return add(scale_channels(x, s), res)
     return _ScaleChannelsAdd.apply(x.contiguous(), s.contiguous(), res.contiguous())
+
+
+class _GlobalAvgPoolPassBF16(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) of a bf16 NHWC map -> (pooled fp32 [N, C], x') where x' is x for its other consumer (the gated product of
+    the SE module); the two gradients meet in ONE pass: gx = g_x' + g_pooled[n][c] / (H W)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, dtype=BF16)
+        n, h, w, c = x.shape
+        pooled = torch.empty((n, c), device=x.device, dtype=torch.float32)
+        ws = _parts_ws(x.device, 64 * n * c)
+        _L().global_avgpool_bf16(_p(x), _p(pooled), _p(ws), ws.numel(), n, h * w, c, _st())
+        ctx.shape = x.shape
+        return pooled, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gp, gx_pass):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, device=gp.device, dtype=BF16)
+        _L().add_bcast_bf16(_p(gx_pass.contiguous()), _p(gp.contiguous()), _p(gx), n, h * w, c, _st())
+        return gx
+
+
+def global_avg_pool_pass_bf16(x):
+    return _GlobalAvgPoolPassBF16.apply(x.contiguous())
 
 
 class _SqSumLast(torch.autograd.Function):
@@ -1670,10 +1731,11 @@ def sigmoid(x):
 class _PReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, a):
-        _chk(x, a)
+        _chk(x, dtype=x.dtype)
+        _chk(a)
         c = x.shape[-1]
         y = torch.empty_like(x)
-        _L().prelu_f32(_p(x), _p(a), _p(y), x.numel() // c, c, _st())
+        (_L().prelu_bf16 if x.dtype == BF16 else _L().prelu_f32)(_p(x), _p(a), _p(y), x.numel() // c, c, _st())
         ctx.save_for_backward(x, a)
         return y
 
@@ -1681,6 +1743,11 @@ class _PReLU(torch.autograd.Function):
     def backward(ctx, g):
         x, a = ctx.saved_tensors
         c = x.shape[-1]
+        if x.dtype == BF16:
+            gx, ga = torch.empty_like(x), torch.empty_like(a)
+            ws = _parts_ws(x.device, 512 * c)
+            _L().prelu_bwd_bf16(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), _p(ws), ws.numel(), x.numel() // c, c, _st())
+            return gx, ga
         gx, ga = torch.empty_like(x), _zeros_like(a)
         ws = _parts_ws(x.device, 1024 * c)
         _L().prelu_bwd_f32(_p(g.contiguous()), _p(x), _p(a), _p(gx), _p(ga), _p(ws), ws.numel(), x.numel() // c, c, _st())
@@ -1695,18 +1762,18 @@ def prelu(x, a):
 class _Subsample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stride):
-        _chk(x)
+        _chk(x, dtype=x.dtype)
         n, h, w, c = x.shape
-        y = torch.empty((n, (h - 1) // stride + 1, (w - 1) // stride + 1, c), device=x.device, dtype=torch.float32)
-        _L().subsample_f32(_p(x), _p(y), n, h, w, c, stride, 0, _st())
+        y = torch.empty((n, (h - 1) // stride + 1, (w - 1) // stride + 1, c), device=x.device, dtype=x.dtype)
+        (_L().subsample_bf16 if x.dtype == BF16 else _L().subsample_f32)(_p(x), _p(y), n, h, w, c, stride, 0, _st())
         ctx.cfg = (x.shape, stride)
         return y
 
     @staticmethod
     def backward(ctx, g):
         (n, h, w, c), stride = ctx.cfg
-        gx = torch.empty((n, h, w, c), device=g.device, dtype=torch.float32)
-        _L().subsample_f32(_p(g.contiguous()), _p(gx), n, h, w, c, stride, 1, _st())
+        gx = torch.empty((n, h, w, c), device=g.device, dtype=g.dtype)
+        (_L().subsample_bf16 if g.dtype == BF16 else _L().subsample_f32)(_p(g.contiguous()), _p(gx), n, h, w, c, stride, 1, _st())
         return gx, None
 
 
@@ -1726,7 +1793,9 @@ class _BatchNormTrain(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps, groups=1, passthrough=False):
         """passthrough: x itself is returned as a fourth output for x's OTHER consumer (the identity shortcut of an IR block); its
         gradient then arrives here and joins gx inside the backward kernel instead of in a separate accumulation pass"""
-        _chk(x, gamma, beta)
+        b16 = x.dtype == BF16  # bf16 activations (IR-SE50 body of the pSp encoder): fp32 statistics / parameters, bf16 in and out
+        _chk(x, dtype=x.dtype)
+        _chk(gamma, beta)
         lib = _L()
         c = x.shape[-1]
         if x.shape[0] % groups:
@@ -1734,9 +1803,10 @@ class _BatchNormTrain(torch.autograd.Function):
         rows = x.numel() // c // groups
         sums, ws = _norm_ws(x.device, groups, c)
         stats = torch.empty((groups, c, 2), device=x.device, dtype=torch.float32)
-        lib.instnorm_stats_f32(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), groups, rows, c, eps, C.c_void_p(ws.data_ptr()), ws.numel(), _st())
+        (lib.instnorm_stats_bf16 if b16 else lib.instnorm_stats_f32)(_p(x), C.c_void_p(sums.data_ptr()), _p(stats), groups, rows, c, eps,
+                                                                      C.c_void_p(ws.data_ptr()), ws.numel(), _st())
         y = torch.empty_like(x)
-        lib.instnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), groups, rows, c, 1.0, _st())
+        (lib.instnorm_apply_bf16 if b16 else lib.instnorm_apply_f32)(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), groups, rows, c, 1.0, _st())
         ctx.save_for_backward(x, stats, gamma, beta)
         ctx.groups = groups
         ctx.mark_non_differentiable(stats, sums)
@@ -1756,9 +1826,15 @@ class _BatchNormTrain(torch.autograd.Function):
         rows = x.numel() // c // groups
         g = g.contiguous()
         red, ws = _norm_ws(x.device, groups, c)
+        gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
+        if x.dtype == BF16:
+            lib.instnorm_bwd_reduce_bf16(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), groups, rows, c, 1.0,
+                                         C.c_void_p(ws.data_ptr()), ws.numel(), _st())
+            lib.instnorm_bwd_apply_bf16(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()),
+                                        _p(gpass.contiguous()) if gpass is not None else None, _p(gx), _p(dg), _p(db), groups, rows, c, 1.0, _st())
+            return gx, dg, db, None, None, None
         lib.instnorm_bwd_reduce_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), groups, rows, c, 1.0,
                                     C.c_void_p(ws.data_ptr()), ws.numel(), _st())
-        gx, dg, db = torch.empty_like(x), _zeros_like(gamma), _zeros_like(beta)
         if gpass is not None:
             lib.instnorm_bwd_apply_add_f32(_p(x), _p(g), _p(stats), _p(gamma), _p(beta), C.c_void_p(red.data_ptr()), _p(gpass.contiguous()),
                                            _p(gx), _p(dg), _p(db), groups, rows, c, 1.0, _st())

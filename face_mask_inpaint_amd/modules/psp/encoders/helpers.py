@@ -69,6 +69,9 @@ def batch_norm(bn: BatchNorm2d, x, passthrough=False):
                     bn.running_var.mul_(1 - m).add_(var, alpha=m)
                     bn.num_batches_tracked += 1
         return y
+    if x.dtype == torch.bfloat16:  # eval-mode BatchNorm of a bf16 body: evaluated in fp32 (inference path, not the benchmarked one)
+        y = batch_norm(bn, x.float()).to(torch.bfloat16)
+        return (y, x) if passthrough else y
     # eval mode: frozen statistics, but the affine parameters still receive gradients like torch.nn.BatchNorm2d's do
     # ([C]-sized torch bookkeeping; the per-pixel work and its reductions are the library's)
     want = torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)
@@ -89,11 +92,19 @@ class SEModule(Module):
         self.sigmoid = Sigmoid()
 
     def gate(self, x):
-        """the [N, C] channel gates sigmoid(fc2(relu(fc1(avgpool(x)))))"""
+        """the [N, C] channel gates sigmoid(fc2(relu(fc1(avgpool(x))))) (fp32)"""
         n, h, w, c = x.shape
         s = FF.avg_pool(x, h) if h == w else FF.adaptive_avg_pool(x, 1, 1)  # AdaptiveAvgPool2d(1) -> [N,1,1,C]
         s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
         return FF.sigmoid(run_conv(self.fc2, s)).view(n, c)
+
+    def gate_bf16(self, x):
+        """bf16 activations: (gates fp32 [N, C], x') -- x' is x handed on to the gated product so that both gradients of x meet in
+        one kernel (functional._GlobalAvgPoolPassBF16); the two tiny fully-connected layers stay fp32"""
+        n, h, w, c = x.shape
+        pooled, xp = FF.global_avg_pool_pass_bf16(x)
+        s = FF.leaky_relu(run_conv(self.fc1, pooled.view(n, 1, 1, c)), 0.0)
+        return FF.sigmoid(run_conv(self.fc2, s)).view(n, c), xp
 
     def nhwc(self, x):
         with weight_scope(self):
@@ -118,6 +129,9 @@ class _Bottleneck(Module):
             r = FF.prelu(r, self.res_layer[2].weight)
             r = run_conv(self.res_layer[3], r)
             r = batch_norm(self.res_layer[4], r)
+            if len(self.res_layer) > 5 and r.dtype == torch.bfloat16:
+                gates, rp = self.res_layer[5].gate_bf16(r)
+                return FF.scale_channels_add(rp, gates, sc)
             if len(self.res_layer) > 5 and _FUSE:  # SE gate and residual add in one pass
                 return FF.scale_channels_add(r, self.res_layer[5].gate(r), sc)
             if len(self.res_layer) > 5:

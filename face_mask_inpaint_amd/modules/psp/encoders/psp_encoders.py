@@ -60,6 +60,11 @@ class GradualStyleEncoder(Module):
             self.styles.append(GradualStyleBlock(w4, w4, _spatial[0] if i < self.coarse_ind else (_spatial[1] if i < self.middle_ind else _spatial[2])))
         self.latlayer1 = nn.Conv2d(w3, w4, kernel_size=1, stride=1, padding=0)
         self.latlayer2 = nn.Conv2d(w2, w4, kernel_size=1, stride=1, padding=0)
+        # opts.encoder_dtype ("fp32" default / "bf16", this build's option like opts.decoder_dtype): the 24 IR-SE blocks keep bf16 NHWC
+        # activations between the bf16 MFMA convolutions (fp32 accumulation, fp32 parameters / BatchNorm statistics / SE gates and all
+        # parameter gradients); the C = 3 stem, the attention blocks, the FPN and the style heads stay fp32
+        dt = getattr(opts, "encoder_dtype", "fp32")
+        self.body_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}.get(dt, dt)
         self.use_attention = opts.use_attention
         if opts.use_attention:
             self.attention1 = ExampleGuidedAttention(w4, out_channels=w4)
@@ -68,11 +73,14 @@ class GradualStyleEncoder(Module):
     def _pyramid(self, x):
         x = run_conv(self.input_layer[0], x)
         x = FF.prelu(batch_norm(self.input_layer[1], x), self.input_layer[2].weight)
+        b16 = self.body_dtype == torch.bfloat16 and self.training
+        if b16:
+            x = x.to(torch.bfloat16)
         taps = {}
         for i, l in enumerate(self.body):
             x = l.nhwc(x)
             if i in (6, 20, 23):
-                taps[i] = x
+                taps[i] = x.float() if b16 else x
         return taps[6], taps[20], taps[23]  # [N,64,64,128], [N,32,32,256], [N,16,16,512]
 
     @staticmethod

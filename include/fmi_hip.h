@@ -283,6 +283,29 @@ int fmi_vae_sample_bwd_f32(const float* gz, const float* o_src, const float* o_r
 /* k x k mean pooling, stride k (nn.AvgPool2d(2,2) base_function.py:233; AdaptiveAvgPool2d 1024->256 model.py:79) */
 int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, int C, int k, void* stream);
 int fmi_avgpool_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int k, void* stream);
+/* ---- bf16 activations for the IR-SE50 body of the pSp encoder (helpers.py:56-119; SURVEY.md 8a part B: bf16 compute, fp32
+ * accumulate / parameters): NHWC bf16 tensors, fp32 statistics, slopes, gates and reduction results.  C % 8 == 0 (C % 4 for the norms).
+ * The BatchNorm2d kernels are the instance-norm kernels above on bf16 tensors (gadd of the backward may be NULL). ---- */
+int fmi_instnorm_stats_bf16(const uint16_t* x, double* sums, float* stats, int N, int HW, int C, float eps, double* ws, int64_t ws_doubles,
+                            void* stream);
+int fmi_instnorm_apply_bf16(const uint16_t* x, const float* stats, const float* gamma, const float* beta, uint16_t* y, int N, int HW, int C,
+                            float slope, void* stream);
+int fmi_instnorm_bwd_reduce_bf16(const uint16_t* x, const uint16_t* gy, const float* stats, const float* gamma, const float* beta, double* red,
+                                 int N, int HW, int C, float slope, double* ws, int64_t ws_doubles, void* stream);
+int fmi_instnorm_bwd_apply_bf16(const uint16_t* x, const uint16_t* gy, const float* stats, const float* gamma, const float* beta,
+                                const double* red, const uint16_t* gadd, uint16_t* gx, float* dgamma, float* dbeta, int N, int HW, int C,
+                                float slope, void* stream);
+/* nn.PReLU(C) (helpers.py:105) and its backward; ga[C] is WRITTEN (partials workspace ws of >= C floats, ideally 512 C) */
+int fmi_prelu_bf16(const uint16_t* x, const float* a, uint16_t* y, int64_t rows, int C, void* stream);
+int fmi_prelu_bwd_bf16(const uint16_t* g, const uint16_t* x, const float* a, uint16_t* gx, float* ga, float* ws, int64_t ws_floats, int64_t rows,
+                       int C, void* stream);
+/* SE gate x residual add (helpers.py:64-72,116-118), plain residual add, AdaptiveAvgPool2d(1) -> fp32 [N][C] (ws >= N C floats), the
+ * gradient of the pooled branch joined with the scaled branch's (gx = g + gpool[n][c] / P), MaxPool2d(1, stride) and its backward */
+int fmi_scale_channels_add_bf16(const uint16_t* x, const float* s, const uint16_t* res, uint16_t* y, int N, int64_t P, int C, void* stream);
+int fmi_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, void* stream);
+int fmi_global_avgpool_bf16(const uint16_t* x, float* pooled, float* ws, int64_t ws_floats, int N, int64_t P, int C, void* stream);
+int fmi_add_bcast_bf16(const uint16_t* g, const float* gpool, uint16_t* gx, int N, int64_t P, int C, void* stream);
+int fmi_subsample_bf16(const uint16_t* x, uint16_t* y, int N, int H, int W, int C, int stride, int backward, void* stream);
 /* y = x * s[n][c] + res: SE gate and residual add of a bottleneck_IR_SE block (helpers.py:64-72,116-118) in one pass (C % 4 == 0) */
 int fmi_scale_channels_add_f32(const float* x, const float* s, const float* res, float* y, int N, int64_t P, int C, void* stream);
 /* fmi_instnorm_bwd_apply_f32 with gx += gadd: the gradient of a second consumer of x (the identity shortcut of an IR block) joins in the
