@@ -123,7 +123,7 @@ SCRIPT_LOSS_ARGS = dict(id_lambda=0.1, lpips_lambda=0.8, l2_lambda=2.0, style_la
                         w_norm_lambda=0.0, start_from_latent_avg=True)
 
 
-def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None, graph=False):
+def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, train_decoder=True, loss_args=None, graph=False, encoder_dtype="fp32"):
     """one train_psp.py step loop (train_psp.py:307-335): pSp forward (GradualStyleEncoder on src + ref with attention, StyleGAN2
     decoder of ``size``), pSpLoss, backward, fused Adam over the encoder (+ decoder when train_decoder, as scripts/train_psp.sh runs
     it).  Returns (seconds for ``steps`` steps, per-launch summary of one extra profiled step).
@@ -137,7 +137,7 @@ def train_leg(dev, decoder_dtype="bf16", size=256, batch=16, steps=5, warmup=2, 
 
     torch.manual_seed(0)
     opts = types.SimpleNamespace(output_size=size, encoder_type="GradualStyleEncoder", train_decoder=train_decoder, use_attention=True, pt_ckpt_path=None,
-                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype=decoder_dtype)
+                                 stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype=decoder_dtype, encoder_dtype=encoder_dtype)
     net = pSp(opts).to(dev).train()
     net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
     crit = pSpLoss(types.SimpleNamespace(**(loss_args or LOSS_ARGS)))

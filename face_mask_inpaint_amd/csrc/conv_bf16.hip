@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvSetB set) {
   const int nt_all = (K + BK - 1) / BK, per = (nt_all + set.ksplit - 1) / set.ksplit;
   const int kt0 = blockIdx.z * per;
   const int nt = (kt0 + per <= nt_all ? per : nt_all - kt0);  // reduction tiles of this split (may be <= 0)
-  if (nt <= 0) return;
+  // no reduction tile for this split: nothing to add -- EXCEPT a phase with an empty reduction (K = 0: the three tap-less sub-pixel
+  // phases of the adjoint of a 1x1 stride-2 convolution, the IR-SE shortcut of the pSp encoder), whose outputs are zeros that must be
+  // WRITTEN when the result goes straight to y (with a zero-initialised split workspace they already are)
+  if (nt <= 0 && (K > 0 || blockIdx.z > 0 || set.ws)) return;
   const int nw = (BM * CPR % NT == 0 && BN * CPR % NT == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
 #pragma unroll
   for (int p = 0; p < DEPTH; ++p)

@@ -8,8 +8,9 @@ dd, size, batch, td = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), bool(int(
 graph = "graph" in sys.argv[5:]
 la = B.SCRIPT_LOSS_ARGS if "script" in sys.argv[5:] else None
 steps = 6
-dt, summ = B.train_leg(torch.device("cuda:0"), dd, size, batch, steps, 2, train_decoder=td, graph=graph, loss_args=la)
-print(f"{dd} {size} bs{batch} train_decoder={td} graph={graph} script_loss={la is not None}: {dt / steps * 1e3:.1f} ms per step (wall), {batch * steps / dt:.1f} images/s; profiled step: {summ}")
+ed = "bf16" if "enc16" in sys.argv[5:] else "fp32"
+dt, summ = B.train_leg(torch.device("cuda:0"), dd, size, batch, steps, 2, train_decoder=td, graph=graph, loss_args=la, encoder_dtype=ed)
+print(f"{dd} {size} bs{batch} train_decoder={td} graph={graph} script_loss={la is not None} encoder={ed}: {dt / steps * 1e3:.1f} ms per step (wall), {batch * steps / dt:.1f} images/s; profiled step: {summ}")
 if "table" in sys.argv[5:]:  # per-call-site launch table of one eager step
     from collections import defaultdict
     from face_mask_inpaint_amd import functional as FF
