@@ -140,7 +140,7 @@ struct ConvPhaseB {
 };
 struct ConvSetB {
   ConvPhaseB ph[4];
-  int N, tiles_n, ksplit, dbg_skip_empty;
+  int N, tiles_n, ksplit;
   float* ws;  // split reduction: fp32 twin of the output (zeroed by the caller), partial sums meet through atomics
 };
 
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvSetB set) {
   // no reduction tile for this split: nothing to add -- EXCEPT a phase with an empty reduction (K = 0: the three tap-less sub-pixel
   // phases of the adjoint of a 1x1 stride-2 convolution, the IR-SE shortcut of the pSp encoder), whose outputs are zeros that must be
   // WRITTEN when the result goes straight to y (with a zero-initialised split workspace they already are)
-  if (nt <= 0 && (K > 0 || blockIdx.z > 0 || set.ws || set.dbg_skip_empty)) return;
+  if (nt <= 0 && (K > 0 || blockIdx.z > 0 || set.ws)) return;
   const int nw = (BM * CPR % NT == 0 && BN * CPR % NT == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
 #pragma unroll
   for (int p = 0; p < DEPTH; ++p)
@@ -349,8 +349,6 @@ static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws,
     if (set.ph[p].K > Kmax) Kmax = set.ph[p].K;
   }
   set.N = N;
-  static const int dbg_skip = getenv("FMI_BF16_EMPTY_OFF") ? 1 : 0;  // debug A/B: the pre-fix behaviour (empty phases not written)
-  set.dbg_skip_empty = dbg_skip;
   const bool can_split = ws && ws_floats >= out_elems && out_elems % 4 == 0 && !set.ph[0].ep.colscale;
 #define FMI_LAUNCH_B(TILE)                                                                                                        \
   do {                                                                                                                            \

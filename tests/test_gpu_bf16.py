@@ -316,10 +316,6 @@ def test_bf16_irse_body_tracks_fp32(dev):
     for (n, p), (_, q) in zip(e32.named_parameters(), e16.named_parameters()):
         if p.grad is not None and p.ndim > 1:
             rels.append((float((q.grad - p.grad).norm() / (p.grad.norm() + 1e-30)), n))
-    if __import__("os").environ.get("FMI_DBG_PER_TENSOR"):
-        for r, n in rels:
-            if "res_layer.1.weight" in n or "shortcut" in n or "styles.0" in n or "latlayer" in n:
-                print("   %.3e %s" % (r, n))
     rels.sort()
     print("bf16 IR-SE body vs fp32: codes %.2e of range; weight-gradient relative L2 error median %.2e p90 %.2e worst %.2e (%s)" % (
         err / scale, rels[len(rels) // 2][0], rels[int(0.9 * len(rels))][0], rels[-1][0], rels[-1][1]))
