@@ -16,9 +16,8 @@
 //    reference by more than 20 (fp32 has the range; p <= e^20), which happens in the first tiles only; the branch is
 //    wave-uniform.
 #include "common.h"
+#include "x6.h"
 #include <cstdlib>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ATT_THR 20.0f
 
@@ -170,6 +169,196 @@ __global__ void __launch_bounds__(NW * 64, 1) attn_fwd_kernel(const float* __res
   if (lh == 0 && lse) lse[row] = mref + logf(lsum);
 }
 
+
+// =====================================================================================================
+// Forward on the bf16 matrix pipe (x6.h): the same flash structure, every product as six bf16 MFMAs of K = 16 on exact three-way
+// splits of the fp32 operands.
+//  * the K / V tile of 32 keys is split ONCE, on its way from the staging registers into LDS, into three bf16 images each:
+//      K pieces  [32 keys][D bf16],  row pitch 2 D + 16 bytes: the A fragment (key = lane, 8 consecutive d) is one ds_read_b128;
+//      V pieces  [32 keys][CT bf16], row pitch 2 CT + 64 bytes: the A fragment of O^T += V^T P^T (channel = lane, keys in the
+//                reduction) is two ds_read_b64_tr_b16 -- the hardware transposes a 4-key x 16-channel block per 16 lanes;
+//  * Q pieces stay in registers (B operand of S^T = K Q^T), and the exponentiated tile, still one query per lane column, is cut
+//    into its three pieces in registers: element j of lane half h of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3), the order
+//    the score tile's registers already have, so the V reads simply address those keys;
+//  * per 32-key tile and wave: 6 x (D / 16 + 2 NCT) MFMAs (120 at D = 64, C = 256: 3 840 matrix-pipe cycles against 10 240 for the
+//    160 fp32 MFMAs), ~110 VALU instructions for the K / V split and 88 for P.
+// =====================================================================================================
+template <int D, int NCT, int NW>
+__global__ void __launch_bounds__(NW * 64, 1) attn_fwd_x6_kernel(const float* __restrict__ q, const float* __restrict__ v1,
+                                                                 const float* __restrict__ v2, float* __restrict__ o1,
+                                                                 float* __restrict__ o2, float* __restrict__ lse, int T, int C1,
+                                                                 int C2) {
+  constexpr int CT = NCT * 32;
+  constexpr int KP = 2 * D + 16, VP = 2 * CT + 64;          // row pitches (bytes)
+  constexpr int KIMG = 32 * KP, VIMG = 32 * VP;             // one piece image
+  constexpr int STAGE = 3 * KIMG + 3 * VIMG;                // bytes per stage
+  constexpr int NTH = NW * 64;
+  constexpr int NKL = (8 * D + NTH - 1) / NTH;              // float4 loads per thread for a K tile
+  constexpr int NVL = (8 * CT) / NTH;                       // float4 loads per thread for a V tile
+  static_assert((8 * CT) % NTH == 0, "whole float4 passes over the V tile");
+  static_assert(D % 16 == 0, "whole bf16 k-steps");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x6[];
+  typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem_x6;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.y;
+  const int q0 = blockIdx.x * (NW * 32) + wid * 32;
+  const float* qb = q + (int64_t)n * T * D;
+  const float* v1b = v1 + (int64_t)n * T * C1;
+  const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
+
+  // this lane's query pieces: B[k = d][col = query], d = 16 kk + 8 lh + j
+  bf16x8_t qp[D / 16][3];
+#pragma unroll
+  for (int kk = 0; kk < D / 16; ++kk) {
+    const float4 a = *reinterpret_cast<const float4*>(qb + (int64_t)(q0 + l31) * D + 16 * kk + 8 * lh);
+    const float4 b = *reinterpret_cast<const float4*>(qb + (int64_t)(q0 + l31) * D + 16 * kk + 8 * lh + 4);
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    split3_bf16(f, qp[kk]);
+  }
+
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  float mref = -INFINITY, lsum = 0.f;
+
+  // staging: split each float4 into three 8-byte pieces and store them into the images of stage `st`
+  float4 rk[NKL], rv[NVL];
+  auto lstore = [&](int st) {
+    unsigned char* base = smem_x6 + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+      const int f = tid + NTH * i;
+      if (f < 8 * D) {
+        const int key = f / (D / 4), dq = f % (D / 4);
+        uint32_t a0, a1, a2, b0, b1, b2;
+        split3_pair(rk[i].x, rk[i].y, a0, a1, a2);
+        split3_pair(rk[i].z, rk[i].w, b0, b1, b2);
+        unsigned char* d = base + key * KP + dq * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(d + KIMG) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(d + 2 * KIMG) = make_uint2(a2, b2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + NTH * i;
+      const int key = f / (CT / 4), c4 = f % (CT / 4);
+      uint32_t a0, a1, a2, b0, b1, b2;
+      split3_pair(rv[i].x, rv[i].y, a0, a1, a2);
+      split3_pair(rv[i].z, rv[i].w, b0, b1, b2);
+      unsigned char* d = base + 3 * KIMG + key * VP + c4 * 8;
+      *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+      *reinterpret_cast<uint2*>(d + VIMG) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(d + 2 * VIMG) = make_uint2(a2, b2);
+    }
+  };
+  // transposed V fragment reads: lane 4 q + p of a 16-lane group addresses key row q, channels 4 p .. 4 p + 3 of the group's 16
+  const int i16 = lane & 15;
+  const uint32_t vlane = (uint32_t)((4 * lh + (i16 >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
+  const uint32_t klane = (uint32_t)(l31 * KP + 16 * lh);
+
+  att_gload<D, CT, NKL, NVL, NTH>(rk, rv, qb, v1b, v2b, C1, C2, 0, tid);
+  lstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    // unconditional prefetch (the last iteration re-reads its own tile): a conditional one sends rk/rv to scratch
+    att_gload<D, CT, NKL, NVL, NTH>(rk, rv, qb, v1b, v2b, C1, C2, k0 + 32 < T ? k0 + 32 : k0, tid);
+    const uint32_t kimg = lds0 + (uint32_t)(buf * STAGE) + klane;
+    const uint32_t vimg = lds0 + (uint32_t)(buf * STAGE + 3 * KIMG) + vlane;
+    // S^T[key][query] for 32 keys x this wave's 32 queries
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) {
+      bf16x8_t kp[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        typedef __attribute__((address_space(3))) bf16x8_t* lp8;
+        kp[pc] = *(lp8)(uintptr_t)(kimg + (uint32_t)(pc * KIMG + kk * 32));
+      }
+      st = mfma_x6(kp, qp[kk], st);
+    }
+    // online softmax, one query per lane column (keys split over the lane pair l, l^32)
+    float tmax = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (__any(tmax > mref + ATT_THR)) {
+      const float mnew = fmaxf(mref, tmax);
+      const float alpha = __expf(mref - mnew);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] *= alpha;
+      lsum *= alpha;
+      mref = mnew;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = __expf(st[r] - mref);
+      psum += st[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    lsum += psum;
+    // O^T[c][query] += V^T[c][key] P^T[key][query]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t pp[3];
+      {
+        const float f[8] = {st[8 * s], st[8 * s + 1], st[8 * s + 2], st[8 * s + 3], st[8 * s + 4], st[8 * s + 5], st[8 * s + 6], st[8 * s + 7]};
+        split3_bf16(f, pp);
+      }
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        bf16x8_t vp[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          typedef short s16x4_t __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4_t* lp4;
+          const uint32_t ad = vimg + (uint32_t)(pc * VIMG + 16 * s * VP + 64 * c);
+          union {
+            s16x4_t h[2];
+            bf16x8_t v;
+          } u;
+          u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)ad);
+          u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)(ad + 8 * VP));
+          vp[pc] = u.v;
+        }
+        acc[c] = mfma_x6(vp, pp, acc[c]);
+      }
+    }
+    lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: register r of tile c is channel c*32 + (r&3) + 8*(r>>2) + 4*lh of query q0 + l31
+  const float inv = 1.f / lsum;
+  const int64_t row = (int64_t)n * T + q0 + l31;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int cbase = c * 32;
+    float* ob = (cbase < C1) ? o1 + row * C1 + cbase : o2 + row * C2 + (cbase - C1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 o;
+      o.x = acc[c][4 * g + 0] * inv;
+      o.y = acc[c][4 * g + 1] * inv;
+      o.z = acc[c][4 * g + 2] * inv;
+      o.w = acc[c][4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(ob + 8 * g + 4 * lh) = o;
+    }
+  }
+  if (lh == 0 && lse) lse[row] = mref + logf(lsum);
+}
+
 extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const float* v2, float* o1, float* o2, float* lse,
                                      int N, int T, int D, int C1, int C2, void* stream) {
   if (!q || !v1 || !o1 || N <= 0 || T <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && (!v2 || !o2))) return FMI_ERR_BAD_ARG;
@@ -181,11 +370,26 @@ extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const floa
   const int nct = (C1 + C2) / 32;
   const dim3 grid(T / (nw * 32), N), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;
-#define ATT_LAUNCH(DD, NN)                                                                                                    \
+#if FMI_X6
+#define ATT_LAUNCH1(DD, NN, WW)                                                                                                \
   do {                                                                                                                        \
-    if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 8>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2);      \
-    else if (nw == 2) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 2>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2); \
-    else hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, 4>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2);              \
+    constexpr int lds_bytes = 2 * 3 * 32 * ((2 * DD + 16) + (2 * NN * 32 + 64));                                               \
+    static bool attr_set = false; /* > 64 KB of dynamic LDS must be opted into once per kernel */                              \
+    if (!attr_set) {                                                                                                          \
+      if (hipFuncSetAttribute((const void*)attn_fwd_x6_kernel<DD, NN, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) \
+        return FMI_ERR_LAUNCH;                                                                                                \
+      attr_set = true;                                                                                                        \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((attn_fwd_x6_kernel<DD, NN, WW>), grid, block, lds_bytes, st, q, v1, v2, o1, o2, lse, T, C1, C2);       \
+  } while (0)
+#else
+#define ATT_LAUNCH1(DD, NN, WW) hipLaunchKernelGGL((attn_fwd_kernel<DD, NN, WW>), grid, block, 0, st, q, v1, v2, o1, o2, lse, T, C1, C2)
+#endif
+#define ATT_LAUNCH(DD, NN)                 \
+  do {                                     \
+    if (nw == 8) ATT_LAUNCH1(DD, NN, 8);   \
+    else if (nw == 2) ATT_LAUNCH1(DD, NN, 2); \
+    else ATT_LAUNCH1(DD, NN, 4);           \
   } while (0)
   if (D == 64 && nct == 8) ATT_LAUNCH(64, 8);
   else if (D == 32 && nct == 8) ATT_LAUNCH(32, 8);
@@ -195,6 +399,7 @@ extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const floa
   else if (D == 16 && nct == 4) ATT_LAUNCH(16, 4);
   else return FMI_ERR_UNSUPPORTED;
 #undef ATT_LAUNCH
+#undef ATT_LAUNCH1
   return fmi_launch_status();
 }
 

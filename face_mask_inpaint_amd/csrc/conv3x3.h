@@ -138,12 +138,24 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
       for (int j = 0; j < T::TN; ++j)
 #pragma unroll
         for (int s = 0; s < 8; ++s) fb[j][s] = sb[(kx * 16 + 8 * lh + s) * BN + wn + j * 32 + l31];
+#if FMI_X6
+      bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) split3_bf16(fa[i], pa[i]);
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) split3_bf16(fb[j], pb[j]);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+#else
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
           for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+#endif
     }
   };
 

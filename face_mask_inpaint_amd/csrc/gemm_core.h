@@ -19,7 +19,7 @@ extern "C" long fmi_debug_launch_counter;
 #include <type_traits>
 
 #ifndef FMI_HOST_EMU
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "x6.h"
 #endif
 
 // ---- division by a runtime-invariant 32-bit divisor (Granlund-Montgomery round-up method) ----
@@ -701,6 +701,29 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
   auto compute = [&](int buf) {
     const float* a = As + buf * BK * LDA + wm + l31;
     const float* b = Bs + buf * BK * LDB + wn + l31;
+#if FMI_X6
+    static_assert(BK == 16, "one bf16 k-step per tile");
+    {
+      float ga[T::TM][8], gb[T::TN][8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) ga[i][s] = a[(8 * lh + s) * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) gb[j][s] = b[(8 * lh + s) * LDB + j * 32];
+      }
+      bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) split3_bf16(ga[i], pa[i]);
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) split3_bf16(gb[j], pb[j]);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+      return;
+    }
+#endif
     float fa[BK / 2][T::TM], fb[BK / 2][T::TN];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
@@ -917,12 +940,24 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
         for (int s = 0; s < 8; ++s) fb[j][s] = sb[(8 * lh + s) * BN + wn + j * 32 + l31];
       }
     }
+#if FMI_X6
+    bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) split3_bf16(fa[i], pa[i]);
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) split3_bf16(fb[j], pb[j]);
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+#else
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+#endif
   };
 
   auto wait_copies = [&](int n) {  // s_waitcnt vmcnt(n): at most n of this wave's copies may still be in flight

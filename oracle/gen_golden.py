@@ -81,6 +81,18 @@ class EpsFeeder:
         return e
 
 
+class EpsReplay:
+    """feeds recorded draws back (cast to the requested dtype)"""
+
+    def __init__(self, draws):
+        self.draws, self.i = draws, 0
+
+    def __call__(self, shape, dtype, device):
+        e = self.draws[self.i].to(dtype)
+        self.i += 1
+        return e
+
+
 _ALIAS = re.compile(r"(^|\.)(shortcut\.|model\.\d+\.module\.)")
 
 
@@ -748,6 +760,24 @@ def picnet_variants_fixture():
     fx["variants"] = dict(sd0=sd0, src=src, ref=ref, mask=mask, no_prior=o_np, raw=grad_digest(o_raw, 32768), raw_eps=d_raw[:2], pool=o_pool.detach().clone(), pool_eps=d_pool[:2],
                           gout=w, uv_after_no_prior=uv(sd_a), uv_after_raw=uv(sd_b),
                           gparams={n: grad_digest(p.grad, 512) for n, p in G.named_parameters() if p.grad is not None})
+    # the same 'pool' forward + backward by the reference in float64, restarted from the state the fp32 run started in: the adjudicator
+    # of the gradient check (see picnet_train_fixture)
+    torch.set_default_dtype(torch.float64)
+    try:
+        G64 = ref_model.ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(100, 90)).double()
+        G64.load_state_dict({k: v.double() for k, v in sd_b.items()}, strict=False)
+        tdn._standard_normal = EpsReplay(d_pool)
+        try:
+            o64 = G64(src.double(), ref.double(), src_mask=mask.double())
+        finally:
+            tdn._standard_normal = old
+        (o64 * w.double()).sum().backward()
+        fx["variants"]["gparams64"] = {n: grad_digest(p.grad.float(), 512) for n, p in G64.named_parameters() if p.grad is not None}
+        print("  variants: fp32 vs fp64 output", float((o64.float() - o_pool.detach()).abs().max()))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    r32 = sorted((float((fx["variants"]["gparams"][n]["sample"] - d["sample"]).abs().max()) / float(d["max"]), n) for n, d in fx["variants"]["gparams64"].items())
+    print("  variants: reference fp32 vs fp64 gradient error / max|g|: median %.2e worst %.2e (%s)" % (r32[len(r32) // 2][0], r32[-1][0], r32[-1][1]))
     # ---- mask detector (17 M parameters: seeded) and infer_batch
     md = MaskDetector(n_channels=3, bilinear=True)
     seeded_fill_(md, 91)

