@@ -18,11 +18,11 @@ i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 class ConvDesc(C.Structure):
     """fmi_conv_desc (include/fmi_hip.h)."""
 
-    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode", "dil")]
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode", "dil")] + [("w3", C.c_void_p)]
 
 
 class WeightEntry(C.Structure):
-    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("wf", vp), ("wt", vp), ("sigma", vp), ("rows", i32), ("C", i32), ("taps", i32), ("pad_", i32)]
+    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("wf", vp), ("wt", vp), ("sigma", vp), ("rows", i32), ("C", i32), ("taps", i32), ("pad_", i32), ("wf3", vp), ("wt3", vp)]
 
 
 class WeightGradEntry(C.Structure):

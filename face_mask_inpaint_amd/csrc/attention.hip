@@ -20,6 +20,12 @@
 #include <cstdlib>
 
 #define ATT_THR 20.0f
+#ifndef FMI_BWD_HOIST
+#define FMI_BWD_HOIST 0  // V k-steps whose three bf16 pieces the optimiser may keep in registers across query tiles (12 registers each)
+#endif
+#ifndef FMI_BWD_EXP
+#define FMI_BWD_EXP 0  // timing experiments on the x6 backward (wrong results): 1 no query-side product, 2 one dV tile, 4 one dP step, 8 no dS^T stores
+#endif
 
 template <int D, int CT, int NKL, int NVL, int NTH>
 __device__ __forceinline__ void att_gload(float4 (&rk)[NKL], float4 (&rv)[NVL], const float* __restrict__ qb,
@@ -798,6 +804,340 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
   }
 }
 
+// =====================================================================================================
+// Backward, second structure, on the bf16 matrix pipe (x6.h).  Same roles as attn_bwd2_kernel (a wave owns 32 keys with all value
+// channels; the query tile staged in LDS feeds the four key blocks of the workgroup), every product as six bf16 MFMAs of K = 16:
+//  * the query tile (Q_i, gO_i) is cut into its three bf16 pieces ONCE, on the way from the staging registers into LDS:
+//      gO pieces [32 q][CT], 16-byte chunks XOR-swizzled (chunk ^ (((q & 3) << 2) | ((q >> 2) & 3)) inside each 256-byte window) so
+//      that the SAME image serves the row fragments of dP = gO V^T (ds_read_b128) and the transposed fragments of dV^T = gO^T P
+//      (ds_read_b64_tr_b16), both conflict-free;
+//      Q pieces  [32 q][D], 192-byte rows: row fragments for S, transposed fragments for dK^T = Q^T dS;
+//  * the wave's own K / V rows stay fp32 in registers, laid out as B fragments (8 consecutive reduction indices per lane), and
+//    are split on the fly next to the MFMAs that consume them: three-piece copies of V would need 192 registers on top of the
+//    160 accumulator registers;
+//  * P and dS (lane = key, registers = queries) are split in registers: they are the B operands of dV^T and dK^T as they stand;
+//    for the query-side product dQ = dS K the three dS pieces go through a private [key][q] LDS image and come back transposed
+//    (ds_read_b64_tr_b16) as A fragments;
+//  * the query-side tiles of the four key blocks are summed in LDS (ds_add_f32) before the global atomics, as before.
+// Per query tile and wave: 264 bf16 MFMAs (8 448 matrix-pipe cycles; the fp32 kernel: 352 MFMAs, 22 528 cycles).
+// =====================================================================================================
+template <int D, int NCT>
+__global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __restrict__ q, const float* __restrict__ v1,
+                                                              const float* __restrict__ v2, const float* __restrict__ g1,
+                                                              const float* __restrict__ g2, const float* __restrict__ lse,
+                                                              const float* __restrict__ delta, float* __restrict__ gv1,
+                                                              float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+  constexpr int CT = NCT * 32, LDQ = D + 1, NDT = D / 32;
+  constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
+  constexpr int GP = 2 * CT, GIMG = 32 * GP;   // gO piece image: row pitch, bytes per piece
+  constexpr int QP = 192, QIMG = 32 * QP;      // Q piece image
+  constexpr int TIMG = 32 * 64;                // dS^T piece image: [32 keys][32 q] bf16
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* Gs = smem_b;                                     // [3][32][GP]
+  unsigned char* Qs = Gs + 3 * GIMG;                              // [3][32][QP]
+  float* lse_i = reinterpret_cast<float*>(Qs + 3 * QIMG);         // [32]
+  float* del_i = lse_i + 32;                                      // [32]
+  float* Kw = del_i + 32;                                         // [4][32][LDQ]  each wave's key block, fp32 (B operand of dQ = dS K)
+  unsigned char* Ts = reinterpret_cast<unsigned char*>(Kw + 4 * 32 * LDQ);  // [4][3][32][64 B]  private transposed dS pieces
+  float* RB = reinterpret_cast<float*>(Ts + 4 * 3 * TIMG);        // [4][NDT][16][64]  query-side partial tiles of the four key blocks (LDS float atomics cost ~250 cycles per wave instruction: measured)
+  typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem_b;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int n = blockIdx.y, j0 = blockIdx.x * 128 + wid * 32;   // this wave's keys
+  const float* qb = q + (int64_t)n * T * D;
+  const float* v1b = v1 + (int64_t)n * T * C1;
+  const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
+  const float* g1b = g1 + (int64_t)n * T * C1;
+  const float* g2b = g2 ? g2 + (int64_t)n * T * C2 : nullptr;
+  const float* lseb = lse + (int64_t)n * T;
+  const float* delb = delta + (int64_t)n * T;
+
+  float* kw = Kw + wid * 32 * LDQ;
+  for (int f = lane; f < 8 * D; f += 64) {
+    const int key = f / (D / 4), dd = (f % (D / 4)) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(qb + (int64_t)(j0 + key) * D + dd);
+    float* d = kw + key * LDQ + dd;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  // B fragments of this wave's keys, V[key = l31][16 kk + 8 lh + j], in registers (the K fragments are read from Kw per tile)
+  float vfrag[CT / 16][8];
+#pragma unroll
+  for (int kk = 0; kk < CT / 16; ++kk) {
+    const int c = 16 * kk + 8 * lh;
+    const float* src = (c < C1) ? v1b + (int64_t)(j0 + l31) * C1 + c : v2b + (int64_t)(j0 + l31) * C2 + (c - C1);
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    vfrag[kk][0] = a.x, vfrag[kk][1] = a.y, vfrag[kk][2] = a.z, vfrag[kk][3] = a.w;
+    vfrag[kk][4] = b.x, vfrag[kk][5] = b.y, vfrag[kk][6] = b.z, vfrag[kk][7] = b.w;
+  }
+
+  f32x16 acc_dv[NCT], acc_dk[NDT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dv[c][r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NDT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_dk[c][r] = 0.f;
+
+  float4 rq[NQL], rg[NVL];
+  float rl = 0.f, rd = 0.f;
+  auto gload = [&](int i0) {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (D / 4), dd = (f % (D / 4)) * 4;
+      rq[i] = (f < 8 * D) ? *reinterpret_cast<const float4*>(qb + (int64_t)(i0 + row) * D + dd) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (CT / 4), c = (f % (CT / 4)) * 4;
+      rg[i] = (c < C1) ? *reinterpret_cast<const float4*>(g1b + (int64_t)(i0 + row) * C1 + c)
+                       : *reinterpret_cast<const float4*>(g2b + (int64_t)(i0 + row) * C2 + (c - C1));
+    }
+    rl = lseb[i0 + (tid & 31)];
+    rd = delb[i0 + (tid & 31)];
+  };
+  auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQL; ++i) {
+      const int f = tid + 256 * i;
+      if (f < 8 * D) {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        split3_pair(rq[i].x, rq[i].y, a0, a1, a2);
+        split3_pair(rq[i].z, rq[i].w, b0, b1, b2);
+        unsigned char* d = Qs + (f / (D / 4)) * QP + (f % (D / 4)) * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(d + QIMG) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(d + 2 * QIMG) = make_uint2(a2, b2);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f / (CT / 4), c4 = f % (CT / 4), ch = c4 >> 1;
+      uint32_t a0, a1, a2, b0, b1, b2;
+      split3_pair(rg[i].x, rg[i].y, a0, a1, a2);
+      split3_pair(rg[i].z, rg[i].w, b0, b1, b2);
+      unsigned char* d = Gs + row * GP + 16 * ((ch & ~15) | ((ch ^ swz(row)) & 15)) + 8 * (c4 & 1);
+      *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+      *reinterpret_cast<uint2*>(d + GIMG) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(d + 2 * GIMG) = make_uint2(a2, b2);
+    }
+    if (tid < 32) {
+      lse_i[tid] = rl;
+      del_i[tid] = rd;
+    }
+  };
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lp4;
+  typedef __attribute__((address_space(3))) bf16x8_t* lp8;
+  auto tr2 = [&](uint32_t a0, uint32_t a1) {  // two transposed 4 x 16 blocks -> one 8-element fragment
+    union {
+      s16x4_t h[2];
+      bf16x8_t v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)a0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)a1);
+    // the return data must land in an architectural VGPR: with 160 accumulator registers the allocator also hands out AGPRs as LDS
+    // destinations, and an LDS read into an AGPR stalls the LDS return path (SQ_LDS_DATA_FIFO_FULL 1e10 cycles: 38.7 -> 18.9 ms)
+    asm volatile("" : "+v"(u.v));
+    return u.v;
+  };
+  // per-lane address parts
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, gb = (lane >> 4) & 1;
+  const uint32_t g_row = lds0 + (uint32_t)(l31 * GP);                  // row fragments of gO: + piece, + swizzled chunk
+  const int g_rx = (lh ^ swz(l31)) & 15;                               // chunk (2 kk + lh) ^ swz(row) = (2 kk) ^ g_rx on the low four bits
+  const uint32_t g_tr = lds0 + (uint32_t)((4 * lh + tq) * GP + 8 * (tp & 1));   // transposed fragments of gO: query rows 16 s + 4 lh + tq (+ 8)
+  const int g_tx = (2 * gb + (tp >> 1)) ^ ((tq << 2) | lh);            // chunk 4 ct + 2 gb + (tp >> 1), swizzle of that row ((+8: ^ 2)
+  const uint32_t q_row = lds0 + (uint32_t)(3 * GIMG + l31 * QP + 16 * lh);
+  const uint32_t q_tr = lds0 + (uint32_t)(3 * GIMG + (4 * lh + tq) * QP + (16 * gb + 4 * tp) * 2);
+  const uint32_t t_base = (uint32_t)((unsigned char*)Ts - smem_b) + (uint32_t)(wid * 3 * TIMG);
+  // dS^T image: row = key (64 bytes = 8 slots of four queries); slot (2 g + lh) of key k is stored at slot ^ ((k >> 1) & 7): the 16 keys
+  // one ds_write_b64 group covers then fall on 16 different bank pairs (unswizzled: two)
+  const uint32_t t_wr = lds0 + t_base + (uint32_t)(l31 * 64);                    // + piece, + 8 * ((2 g + lh) ^ t_wx)
+  const int t_wx = (l31 >> 1) & 7;
+  const uint32_t t_tr = lds0 + t_base + (uint32_t)((8 * lh + tq) * 64);          // key rows 16 s + 8 lh + tq (+ 4): + 8 * ((4 gb + tp) ^ swizzle of that row)
+  const int t_rx = (4 * lh) | (tq >> 1);                                         // ((row >> 1) & 7) of the first row; the row 4 further: + 2
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int i0 = 0; i0 < T; i0 += 32) {
+    // ---- S[q][key], dP[q][key]: lane = key, registers = queries
+    f32x16 sp, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sp[r] = 0.f;
+      dp[r] = 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < D / 16; ++kk) {
+      bf16x8_t a[3], b[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(q_row + (uint32_t)(pc * QIMG + kk * 32));
+      float kf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[j] = kw[l31 * LDQ + 16 * kk + 8 * lh + j];
+      split3_bf16(kf, b);
+      sp = mfma_x6(a, b, sp);
+    }
+    {  // software pipeline of depth one, fenced per step: the scheduler would otherwise hoist all 48 fragment reads (192 registers)
+      auto g_frag = [&](int kk, bf16x8_t (&a)[3]) {
+        const uint32_t ad = g_row + (uint32_t)(16 * (((2 * kk) & 15) ^ g_rx) + 16 * ((2 * kk) & ~15));
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(ad + (uint32_t)(pc * GIMG));
+      };
+      bf16x8_t a[3], an[3], b[3];
+      g_frag(0, a);
+#pragma unroll
+      for (int kk = 0; kk < ((FMI_BWD_EXP & 4) ? 1 : CT / 16); ++kk) {
+        if (kk + 1 < CT / 16) g_frag(kk + 1, an);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (kk >= FMI_BWD_HOIST) asm volatile("" : "+v"(vfrag[kk][j]));  // not loop-invariant for the optimiser: it would hoist all 192 piece registers out of the tile loop
+        split3_bf16(vfrag[kk], b);
+        dp = mfma_x6(a, b, dp);
+#ifdef FMI_ATT_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float p = __expf(sp[r] - lse_i[qi]);
+      sp[r] = p;
+      dp[r] = p * (dp[r] - del_i[qi]);
+    }
+    // ---- dV^T[c][key] += gO^T[c][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key];  dS pieces -> private transposed image
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t pp[3], ds[3];
+      {
+        const float f[8] = {sp[8 * s], sp[8 * s + 1], sp[8 * s + 2], sp[8 * s + 3], sp[8 * s + 4], sp[8 * s + 5], sp[8 * s + 6], sp[8 * s + 7]};
+        split3_bf16(f, pp);
+        const float e[8] = {dp[8 * s], dp[8 * s + 1], dp[8 * s + 2], dp[8 * s + 3], dp[8 * s + 4], dp[8 * s + 5], dp[8 * s + 6], dp[8 * s + 7]};
+        split3_bf16(e, ds);
+      }
+#pragma unroll
+      for (int pc = 0; pc < ((FMI_BWD_EXP & 8) ? 0 : 3); ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) u32x2_t* lpu2;
+        const u32x4_t w = __builtin_bit_cast(u32x4_t, ds[pc]);
+        *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s) | lh) ^ t_wx))) = u32x2_t{w[0], w[1]};      // g = 2 s
+        *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s + 2) | lh) ^ t_wx))) = u32x2_t{w[2], w[3]};  // g = 2 s + 1
+      }
+      {
+        auto gt_frag = [&](int c, bf16x8_t (&a)[3]) {
+          const uint32_t ch0 = (uint32_t)(16 * (((4 * c) & 15) ^ g_tx) + 16 * ((4 * c) & ~15));
+          const uint32_t ch1 = (uint32_t)(16 * (((4 * c) & 15) ^ g_tx ^ 2) + 16 * ((4 * c) & ~15));
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            a[pc] = tr2(g_tr + (uint32_t)(pc * GIMG + 16 * s * GP) + ch0, g_tr + (uint32_t)(pc * GIMG + (16 * s + 8) * GP) + ch1);
+        };
+        bf16x8_t a[3], an[3];
+        gt_frag(0, a);
+#pragma unroll
+        for (int c = 0; c < ((FMI_BWD_EXP & 2) ? 1 : NCT); ++c) {
+          if (c + 1 < NCT) gt_frag(c + 1, an);
+          acc_dv[c] = mfma_x6(a, pp, acc_dv[c]);
+#ifdef FMI_ATT_FENCE
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) {
+        bf16x8_t a[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          a[pc] = tr2(q_tr + (uint32_t)(pc * QIMG + 16 * s * QP + 64 * c), q_tr + (uint32_t)(pc * QIMG + (16 * s + 8) * QP + 64 * c));
+        acc_dk[c] = mfma_x6(a, ds, acc_dk[c]);
+      }
+    }
+    bf16x8_t pp_dbg[3];
+    {
+      const float f[8] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], sp[6], sp[7]};
+      if (FMI_BWD_EXP & 64) split3_bf16(f, pp_dbg);
+    }
+    // the next query tile's loads are issued only here: their 40 staging registers would otherwise be live across the dP / dV phases,
+    // where the V fragments, the accumulators and the piece fragments already take the whole file (82 registers went to scratch)
+    __builtin_amdgcn_sched_barrier(0);
+    gload(i0 + 32 < T ? i0 + 32 : i0);
+    // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed image was written by this wave; a wave's LDS operations complete in order
+#pragma unroll
+    for (int c = 0; c < ((FMI_BWD_EXP & 1) ? 0 : NDT); ++c) {
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t a[3], b[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          if (FMI_BWD_EXP & 64) { a[pc] = pp_dbg[pc]; continue; }
+          a[pc] = tr2(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
+                      t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
+        }
+        float kf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = (FMI_BWD_EXP & 16) ? sp[j] : kw[(16 * s + 8 * lh + j) * LDQ + c * 32 + l31];
+        split3_bf16(kf, b);
+        dq = mfma_x6(a, b, dq);
+      }
+      float* rb = RB + ((wid * NDT + c) * 16) * 64 + lane;
+      if (FMI_BWD_EXP & 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += dq[r];
+        if (t == 123.456f) rb[0] = t;
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rb[r * 64] = dq[r];
+    }
+    __syncthreads();   // every wave is done with the query tile; RB holds the four partial dQ tiles
+    // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
+#pragma unroll
+    for (int rr = 0; rr < ((FMI_BWD_EXP & 33) ? 0 : NDT * 4); ++rr) {
+      const int row = wid * NDT * 4 + rr;       // = c*16 + r
+      const int c = row >> 4, r = row & 15;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += RB[((w * NDT + c) * 16 + r) * 64 + lane];
+      atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, sum);
+    }
+    lstore();
+    __syncthreads();
+  }
+
+  // ---- epilogue: dV rows of this wave's keys (plain stores) and the key-side dQ (atomics)
+  const int64_t row = (int64_t)n * T + j0 + l31;
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int ch = c * 32;
+    float* ob = (ch < C1) ? gv1 + row * C1 + ch : gv2 + row * C2 + (ch - C1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(ob + 8 * g + 4 * lh) = make_float4(acc_dv[c][4 * g], acc_dv[c][4 * g + 1], acc_dv[c][4 * g + 2], acc_dv[c][4 * g + 3]);
+  }
+#pragma unroll
+  for (int c = 0; c < NDT; ++c) {
+    float* gqb = gq + row * D + c * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(gqb + (r & 3) + 8 * (r >> 2) + 4 * lh, acc_dk[c][r]);
+  }
+}
+
 // delta[row] = sum_c a1[row][c] b1[row][c] (+ second pair): one wave per row
 __global__ void __launch_bounds__(256) rowdot2_kernel(const float* __restrict__ a1, const float* __restrict__ b1, int C1,
                                                       const float* __restrict__ a2, const float* __restrict__ b2, int C2,
@@ -835,16 +1175,26 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
     auto lds2 = [](int d, int ct) {
       return sizeof(float) * (size_t)(32 * (ct + 1) + 32 * (d + 1) + 64 + 4 * 32 * (d + 1) + 4 * 32 * 33 + 4 * (d / 32) * 16 * 64);
     };
+#if FMI_X6
+#define ATTB2_KERNEL attn_bwd2_x6_kernel
+    auto lds2x = [](int d, int ct) {
+      return (size_t)(3 * 32 * 2 * ct + 3 * 32 * 192 + 64 * 4 + 4 * 32 * (d + 1) * 4 + 4 * 3 * 32 * 64 + 4 * (d / 32) * 16 * 64 * 4);
+    };
+#define ATTB2_LDS(DD, CC) lds2x(DD, CC)
+#else
+#define ATTB2_KERNEL attn_bwd2_kernel
+#define ATTB2_LDS(DD, CC) lds2(DD, CC)
+#endif
 #define ATTB2_LAUNCH(DD, NN)                                                                                             \
   do {                                                                                                                   \
     static bool attr_set2 = false;                                                                                       \
     if (!attr_set2) {                                                                                                    \
-      if (hipFuncSetAttribute((const void*)attn_bwd2_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                              (int)lds2(DD, NN * 32)) != hipSuccess)                                                     \
+      if (hipFuncSetAttribute((const void*)ATTB2_KERNEL<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                              (int)ATTB2_LDS(DD, NN * 32)) != hipSuccess)                                                \
         return FMI_ERR_LAUNCH;                                                                                           \
       attr_set2 = true;                                                                                                  \
     }                                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse,         \
+    hipLaunchKernelGGL((ATTB2_KERNEL<DD, NN>), grid2, block, ATTB2_LDS(DD, NN * 32), st, q, v1, v2, go1, go2, lse,        \
                        (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
     return fmi_launch_status();                                                                                          \
   } while (0)
@@ -853,6 +1203,8 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
     if (D == 32 && nct == 4) ATTB2_LAUNCH(32, 4);
     if (D == 64 && nct == 4) ATTB2_LAUNCH(64, 4);
 #undef ATTB2_LAUNCH
+#undef ATTB2_KERNEL
+#undef ATTB2_LDS
   }
   const dim3 grid(T / 32, N);
   auto lds_bytes = [](int d, int ct) { return sizeof(float) * (size_t)(2 * 32 * (ct + 1) + 2 * 32 * (d + 1) + 64 + 4 * 2 * 1024 + 2 * 32 * 33); };

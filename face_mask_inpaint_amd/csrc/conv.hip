@@ -100,6 +100,10 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   ConvGeom g = fwd_geom(d, x, n_eff);
   ConvK la{x, g};
   ConvWX lb{wf, g, w_bstride, d->K, (d->K % 4 == 0) && aligned16(wf) && (w_bstride % 4 == 0)};
+#ifndef FMI_HOST_EMU
+  // bf16 piece images of the weights (fmi_weight_prepare_f32 writes them): [3][taps][C / 8][K][8]
+  const uint16_t* w3 = (FMI_X6 && batch_w == 1 && d->C % 16 == 0 && aligned16(d->w3)) ? (const uint16_t*)d->w3 : nullptr;
+#endif
   ConvEp ep{y, bias, residual, d->OH, d->OW, 1, 0, 0, d->OH, d->OW, d->y_cstride, act, g.dGW, g.dG,
             (int64_t)d->OH * d->OW * d->y_cstride};
   ep.vec = !ep_scalar() && d->K % 4 == 0 && d->y_cstride % 4 == 0 && aligned16(y) && aligned16(bias) && aligned16(residual);
@@ -109,7 +113,7 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   const bool c3 = !c3_off && !(FMI_EXP & 32) && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0 && d->dil <= 1 &&
                   conv3x3_eligible(x, wf, d->C, d->x_cstride, d->K, (int64_t)d->N * d->H * d->W);
   if (c3) {
-    C3Args ca{x, wf, d->N, d->H, d->W, d->C, d->x_cstride, d->K, 0, make_fastdiv(d->W), make_fastdiv(d->H * d->W)};
+    C3Args ca{x, wf, d->N, d->H, d->W, d->C, d->x_cstride, d->K, 0, make_fastdiv(d->W), make_fastdiv(d->H * d->W), w3};
     if (ks > 1) {
       const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
       hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
@@ -129,8 +133,10 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
     ep.res = nullptr;
     ep.act = 3;
     ep.vec = 0;
+    if (w3 && la.dma_ok()) return launch_gemm(la, ConvWX3{w3, g, (int64_t)d->kh * d->kw * d->C * d->K, d->K}, ep, g.Mdim(), d->K, g.Kdim(), 1, ks, (hipStream_t)stream);
     return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), 1, ks, (hipStream_t)stream);
   }
+  if (w3 && la.dma_ok()) return launch_gemm(la, ConvWX3{w3, g, (int64_t)d->kh * d->kw * d->C * d->K, d->K}, ep, g.Mdim(), d->K, g.Kdim(), 1, 1, (hipStream_t)stream);
 #endif
   return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), batch_w, 1, (hipStream_t)stream);
 }
@@ -154,6 +160,11 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
   const int n_eff = batch_w > 1 ? 1 : d->N;
   const int s = d->stride;
   const int dl = d->dil > 1 ? d->dil : 1;
+#ifndef FMI_HOST_EMU
+  // bf16 piece images of the adjoint's weights: [3][taps][K / 8][C][8]
+  const uint16_t* w3 = (FMI_X6 && batch_w == 1 && d->K % 16 == 0 && aligned16(d->w3)) ? (const uint16_t*)d->w3 : nullptr;
+  const int64_t w3_stride = (int64_t)d->kh * d->kw * d->K * d->C;
+#endif
   if (dl > 1 && s != 1) return FMI_ERR_UNSUPPORTED;  // adjoint of a dilated AND strided convolution: not needed by modules/drn.py
 #ifndef FMI_HOST_EMU
   // Strided adjoints of small feature maps (the stride-2 style heads of the pSp encoder: 512 -> 512 at 16^2 .. 2^2) are a few
@@ -206,7 +217,8 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
         ep.res = nullptr;
         ep.act = 3;
         ep.vec = 0;
-        rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, conv_ksplit(g.Mdim(), d->C, g.Kdim()), (hipStream_t)stream);
+        if (w3 && la.dma_ok()) rc = launch_gemm(la, ConvWX3{w3, g, w3_stride, d->C}, ep, g.Mdim(), d->C, g.Kdim(), 1, conv_ksplit(g.Mdim(), d->C, g.Kdim()), (hipStream_t)stream);
+        else rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, conv_ksplit(g.Mdim(), d->C, g.Kdim()), (hipStream_t)stream);
         if (rc) return rc;
         continue;
       }
@@ -215,7 +227,7 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
       const bool c3 = !c3_off && !(FMI_EXP & 32) && s == 1 && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->dil <= 1 &&
                       conv3x3_eligible(dy, wt, d->K, d->y_cstride, d->C, (int64_t)d->N * d->H * d->W);
       if (c3) {  // adjoint of a 3x3 stride-1 pad-1 convolution = the same convolution of dy with flipped taps
-        C3Args ca{dy, wt, d->N, d->OH, d->OW, d->K, d->y_cstride, d->C, 1, make_fastdiv(d->OW), make_fastdiv(d->OH * d->OW)};
+        C3Args ca{dy, wt, d->N, d->OH, d->OW, d->K, d->y_cstride, d->C, 1, make_fastdiv(d->OW), make_fastdiv(d->OH * d->OW), w3};
         if (ks > 1) {
           const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
           hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
@@ -237,7 +249,13 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
         ep.res = nullptr;
         ep.act = 3;
         ep.vec = 0;
-        rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, ks, (hipStream_t)stream);
+        if (w3 && la.dma_ok()) rc = launch_gemm(la, ConvWX3{w3, g, w3_stride, d->C}, ep, g.Mdim(), d->C, g.Kdim(), 1, ks, (hipStream_t)stream);
+        else rc = launch_gemm(la, lb, ep, g.Mdim(), d->C, g.Kdim(), 1, ks, (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
+      if (w3 && la.dma_ok()) {
+        rc = launch_gemm(la, ConvWX3{w3, g, w3_stride, d->C}, ep, g.Mdim(), d->C, g.Kdim(), 1, 1, (hipStream_t)stream);
         if (rc) return rc;
         continue;
       }

@@ -18,16 +18,20 @@ struct C3Args {
   const float* w;  // packed weights [9][C][Nout]
   int N, H, W, C, cs, Nout, flip;
   FastDiv dW, dHW;
+  const uint16_t* w3;  // W3 kernels: the same weights as bf16 pieces [3][9][C / 8][Nout][8] (ConvWX3 in gemm_core.h)
 };
 
-template <class T>
+// W3: the weight tiles arrive as bf16 piece images ([3 kx][3 pieces][2 channel groups][BN] 16-byte chunks per stage) and are read as
+// ready B fragments; only the activation fragments are split in registers.
+template <class T, bool W3>
 __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
   constexpr int BM = T::BM, BN = T::BN, BK = 16;
   constexpr int RA = ((BM + 2 + 15) / 16) * 16;  // rows of the A image (multiple of the 16 rows one wave instruction writes)
   constexpr int NIA = RA / 16;                   // wave instructions of an A image
-  constexpr int NIB = 3 * BN / 16;               // wave instructions of the three B tiles ([3][16 k][BN])
+  constexpr int NIB = W3 ? 9 * BN / 32 : 3 * BN / 16;  // wave instructions of the three B tiles ([3][16 k][BN] floats, or [3][3][2][BN] chunks)
   constexpr int NLA = (NIA + 3) / 4, NLB = (NIB + 3) / 4;
-  constexpr int STAGE = RA * BK + 3 * BK * BN;  // floats
+  constexpr int STAGE = RA * BK + (W3 ? 3 * 3 * BN * 8 : 3 * BK * BN);  // floats
+  static_assert(!W3 || FMI_X6, "piece images feed the bf16 products");
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -65,11 +69,19 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
     const int p = (j * 4 + wid) * 64 + lane;
-    const int per_tap = 16 * (BN / 4);
-    const int kx = p / per_tap, q = p - kx * per_tap;
-    const int k = q / (BN / 4), n = (q - k * (BN / 4)) * 4;
-    bkx[j] = kx;
-    boff[j] = (n0 + n < a.Nout && kx < 3) ? k * a.Nout + n0 + n : -1;
+    if (W3) {  // chunk p of [3 kx][3 pieces][2 channel groups][BN]; boff = element offset inside a piece image, piece in the high bits of bkx
+      const int per_tap = 3 * 2 * BN;
+      const int kx = p / per_tap, q = p - kx * per_tap;
+      const int piece = q / (2 * BN), r = q - piece * (2 * BN), kg = r / BN, n = r - kg * BN;
+      bkx[j] = kx | (piece << 2);
+      boff[j] = (n0 + n < a.Nout && kx < 3) ? (kg * a.Nout + n0 + n) * 8 : -1;
+    } else {
+      const int per_tap = 16 * (BN / 4);
+      const int kx = p / per_tap, q = p - kx * per_tap;
+      const int k = q / (BN / 4), n = (q - k * (BN / 4)) * 4;
+      bkx[j] = kx;
+      boff[j] = (n0 + n < a.Nout && kx < 3) ? k * a.Nout + n0 + n : -1;
+    }
   }
   const int na_w = (NIA - wid + 3) / 4, nb_w = (NIB - wid + 3) / 4;  // instructions wave `wid` issues per stage
   // x-wrap masks of this lane's fragment rows
@@ -114,8 +126,13 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       if (j >= nb_w) break;
-      const int tap = ky * 3 + bkx[j];
-      const float* g = boff[j] >= 0 ? a.w + ((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) * a.Nout + boff[j] : fmi_chunk_zero;
+      const int tap = ky * 3 + (bkx[j] & 3);
+      const float* g;
+      if (W3)
+        g = boff[j] >= 0 ? (const float*)(a.w3 + (int64_t)(bkx[j] >> 2) * 9 * a.C * a.Nout + (((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) >> 3) * a.Nout * 8 + boff[j])
+                         : fmi_chunk_zero;
+      else
+        g = boff[j] >= 0 ? a.w + ((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) * a.Nout + boff[j] : fmi_chunk_zero;
       glds16(g, sb + (uint32_t)(j * 4096));
     }
   };
@@ -134,16 +151,26 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
         fa[i][0] = v0.x, fa[i][1] = v0.y, fa[i][2] = v0.z, fa[i][3] = v0.w;
         fa[i][4] = v1.x, fa[i][5] = v1.y, fa[i][6] = v1.z, fa[i][7] = v1.w;
       }
+      if (!W3) {
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j)
+        for (int j = 0; j < T::TN; ++j)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) fb[j][s] = sb[(kx * 16 + 8 * lh + s) * BN + wn + j * 32 + l31];
+          for (int s = 0; s < 8; ++s) fb[j][s] = sb[(kx * 16 + 8 * lh + s) * BN + wn + j * 32 + l31];
+      }
 #if FMI_X6
       bf16x8_t pa[T::TM][3], pb[T::TN][3];
 #pragma unroll
       for (int i = 0; i < T::TM; ++i) split3_bf16(fa[i], pa[i]);
 #pragma unroll
-      for (int j = 0; j < T::TN; ++j) split3_bf16(fb[j], pb[j]);
+      for (int j = 0; j < T::TN; ++j) {
+        if (W3) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            pb[j][pc] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const unsigned char*>(sb) + ((kx * 3 + pc) * 2 * BN + lh * BN + wn + j * 32 + l31) * 16);
+        } else {
+          split3_bf16(fb[j], pb[j]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -179,19 +206,29 @@ static bool conv3x3_eligible(const float* x, const float* w, int C, int cs, int 
   return (C & 15) == 0 && (C >= 64 || Nout <= 32) && (cs & 3) == 0 && (Nout & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && pixels < (1ll << 30);
 }
 
+using Tile128x64w = TileCfg<4, 1, 1, 2>;  // 128 x 64 with every wave spanning both column tiles: one activation split per 12 MFMAs
+
 static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, hipStream_t st) {
   const int nit = 3 * (a.C >> 4);
   if (ksplit > nit) ksplit = nit;
   const int it_chunk = (nit + ksplit - 1) / ksplit;
   ksplit = (nit + it_chunk - 1) / it_chunk;
-#define C3_LAUNCH(TILE)                                                                                                       \
+#define C3_LAUNCH_(TILE, W3)                                                                                                  \
   do {                                                                                                                        \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(a.Nout, TILE::BN);                                            \
-    hipLaunchKernelGGL((conv3x3_dma_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, a, ep, M, (int)tn, ksplit, \
+    hipLaunchKernelGGL((conv3x3_dma_kernel<TILE, W3>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, a, ep, M, (int)tn, ksplit, \
                        it_chunk);                                                                                             \
   } while (0)
+#define C3_LAUNCH(TILE) C3_LAUNCH_(TILE, false)
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(a.Nout, bn) * ksplit; };
   const int N = a.Nout;
+#if FMI_X6
+  static const bool w3_off = getenv("FMI_W3_OFF") != nullptr;  // debug A/B: split the weight fragments in registers as well
+  if (a.w3 && N > 32 && !w3_off) {  // 2 x 27 KB of LDS: two workgroups per CU (a 128-column piece tile would leave one)
+    C3_LAUNCH_(Tile128x64w, true);
+    return fmi_launch_status();
+  }
+#endif
   if (N <= 32) {
     C3_LAUNCH(Tile128x32);
   } else if (N <= 64) {
@@ -204,6 +241,7 @@ static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, 
     else C3_LAUNCH(Tile64x128);
   }
 #undef C3_LAUNCH
+#undef C3_LAUNCH_
   return fmi_launch_status();
 }
 #endif

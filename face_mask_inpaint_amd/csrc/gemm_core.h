@@ -256,6 +256,7 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
 
 struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [tap][Cred][Nout]
   static constexpr bool KMODE = false;
+  static constexpr bool SPLIT3 = false;
   const float* p;
   ConvGeom g;  // only the tap algebra and C are used
   int64_t bs;
@@ -300,6 +301,41 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
   __device__ void dstart(DCtx&, int) const {}
   __device__ void advance(DCtx&) const {}
 };
+
+#ifndef FMI_HOST_EMU
+// B operand of forward / adjoint convolution from weights the preparation kernel already cut into bf16 pieces (x6.h):
+//   p3[piece][tap][Cred / 8][Nout][8]   -- one 16-byte chunk = 8 consecutive reduction channels of one output column, which IS the
+// lane's B fragment of v_mfma_f32_32x32x16_bf16; a 16-deep tile of a piece is [2 channel groups][BN] chunks, copied lane-linear by the
+// LDS-DMA and read back with one conflict-free ds_read_b128 per fragment.  No split arithmetic for this operand in the main loop.
+struct ConvWX3 {
+  static constexpr bool KMODE = false;
+  static constexpr bool SPLIT3 = true;
+  const uint16_t* p3;
+  ConvGeom g;  // only the tap algebra and C are used
+  int64_t pstride;  // elements per piece image (all taps of the kernel)
+  int Nout;
+  struct Ctx {};
+  __device__ void set_batch(int) {}
+  __device__ Ctx prep(int) const { return Ctx{}; }
+  __device__ float4 load4(const Ctx&, int, int) const { return zero4(); }  // register-staged path: never taken (dma_ok() is a precondition)
+  __host__ __device__ bool dma_ok() const { return (g.C & 15) == 0 && ((uintptr_t)p3 & 15) == 0; }
+  struct DCtx {
+    int64_t off;  // piece * pstride + (kg * Nout + x) * 8, or -1 for columns beyond Nout
+  };
+  struct Tile {
+    const uint16_t* base;  // chunk row of (tap, first channel group of the tile); nullptr past the last tap
+  };
+  __device__ DCtx dprep3(int piece, int kg, int x) const { return DCtx{x < Nout ? piece * pstride + ((int64_t)kg * Nout + x) * 8 : -1}; }
+  __device__ Tile tile(int k0) const {
+    const int t = (int)fdiv((uint32_t)k0, g.dC);
+    if (t >= g.ntaps()) return Tile{nullptr};
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    return Tile{p3 + (((int64_t)wtap * g.C + (k0 - t * g.C)) >> 3) * Nout * 8};
+  }
+  __device__ const void* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? (const void*)(t.base + d.off) : nullptr; }
+};
+#endif
 
 struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), reduction = anchors
   static constexpr bool KMODE = false;
@@ -808,6 +844,11 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32_kernel(LA la, LB lb, EP ep,
 #ifndef FMI_DMA_ATTR
 #define FMI_DMA_ATTR
 #endif
+template <class L, class = void>
+struct is_split3 : std::false_type {};
+template <class L>
+struct is_split3<L, std::void_t<decltype(L::SPLIT3)>> : std::integral_constant<bool, L::SPLIT3> {};
+
 template <class LA, class LB, class EP, class T>
 __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
                                                            int ksplit, int kchunk) {
@@ -816,8 +857,10 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
 #endif
   constexpr int BM = T::BM, BN = T::BN, BK = 16, NST = FMI_NST, DEPTH = NST - 1;  // DEPTH tiles are copied ahead of the one computed
   // copies: a tile image has BX*4 16-byte chunks = BX/16 wave instructions; wave w issues instructions w, w+4, ...
-  constexpr int NLA = (BM + 63) / 64, NLB = (BN + 63) / 64;
-  constexpr int STAGE = (BM + BN) * BK;  // floats
+  constexpr bool B3 = is_split3<LB>::value;  // B arrives as three bf16 piece images [2 channel groups][BN] x 16 bytes
+  constexpr int NIB3 = 3 * BN / 32;         // wave instructions of the three piece images of a tile
+  constexpr int NLA = (BM + 63) / 64, NLB = B3 ? (NIB3 + 3) / 4 : (BN + 63) / 64;
+  constexpr int STAGE = BM * BK + (B3 ? 3 * BN * 8 : BN * BK);  // floats
   __shared__ __attribute__((aligned(1024))) float lds[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -853,21 +896,27 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
   }
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
-    const int p = j * 256 + tid;
-    int x, k;
-    if (LB::KMODE) {
-      x = p >> 2;
-      k = ((p & 3) ^ ((x >> 2) & 3)) * 4;
+    if constexpr (B3) {  // wave instruction j * 4 + wid of [3 pieces][2 channel groups][BN] chunks
+      const int p = (j * 4 + wid) * 64 + lane;
+      const int piece = p / (2 * BN), r = p - piece * (2 * BN), kg = r / BN, x = r - kg * BN;
+      db[j] = lb.dprep3(piece < 3 ? piece : 0, kg, piece < 3 ? n0 + x : 0x40000000);
     } else {
-      k = p / (BN / 4);
-      x = (p % (BN / 4)) * 4;
+      const int p = j * 256 + tid;
+      int x, k;
+      if (LB::KMODE) {
+        x = p >> 2;
+        k = ((p & 3) ^ ((x >> 2) & 3)) * 4;
+      } else {
+        k = p / (BN / 4);
+        x = (p % (BN / 4)) * 4;
+      }
+      db[j] = lb.dprep(n0 + x, k);
+      lb.dstart(db[j], k_begin);
     }
-    db[j] = lb.dprep(n0 + x, k);
-    lb.dstart(db[j], k_begin);
   }
   // wave-uniform: does copy slot j of this wave exist (tiles narrower than 64 rows fill only waves 0..1)
   const int na_w = (BM % 64 == 0) ? NLA : (wid * 64 < BM * 4 ? 1 : 0);
-  const int nb_w = (BN % 64 == 0) ? NLB : (wid * 64 < BN * 4 ? 1 : 0);
+  const int nb_w = B3 ? (NIB3 - wid + 3) / 4 : ((BN % 64 == 0) ? NLB : (wid * 64 < BN * 4 ? 1 : 0));
 
   f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -903,11 +952,18 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
-      if (BN % 64 != 0 && !nb_w) break;
-      const float* g = lb.chunk(db[j], tb);
-      if (!g) g = fmi_chunk_zero;
-      glds16(g, sb + j * 4096);
-      lb.advance(db[j]);
+      if constexpr (B3) {
+        if (j >= nb_w) break;
+        const void* g = lb.chunk(db[j], tb);
+        if (!g) g = fmi_chunk_zero;
+        glds16((const float*)g, sb + j * 4096);
+      } else {
+        if (BN % 64 != 0 && !nb_w) break;
+        const float* g = lb.chunk(db[j], tb);
+        if (!g) g = fmi_chunk_zero;
+        glds16(g, sb + j * 4096);
+        lb.advance(db[j]);
+      }
     }
   };
   auto compute = [&](int st) {
@@ -929,7 +985,9 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
     }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
-      if (LB::KMODE) {
+      if constexpr (B3) {
+        break;  // the piece fragments are read below
+      } else if (LB::KMODE) {
         const int r = wn + j * 32 + l31, sw = (r >> 2) & 3;
         const float4 v0 = *reinterpret_cast<const float4*>(sb + r * 16 + ((2 * lh) ^ sw) * 4);
         const float4 v1 = *reinterpret_cast<const float4*>(sb + r * 16 + ((2 * lh + 1) ^ sw) * 4);
@@ -945,7 +1003,15 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
 #pragma unroll
     for (int i = 0; i < T::TM; ++i) split3_bf16(fa[i], pa[i]);
 #pragma unroll
-    for (int j = 0; j < T::TN; ++j) split3_bf16(fb[j], pb[j]);
+    for (int j = 0; j < T::TN; ++j) {
+      if constexpr (B3) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          pb[j][pc] = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const unsigned char*>(sb) + pc * (2 * BN * 16) + (lh * BN + wn + j * 32 + l31) * 16);
+      } else {
+        split3_bf16(fb[j], pb[j]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -978,7 +1044,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
     }
   };
   const int nt = (k_end - k_begin + BK - 1) / BK;
-  const int nw = (BM % 64 == 0 && BN % 64 == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
+  const int nw = (!B3 && BM % 64 == 0 && BN % 64 == 0) ? NLA + NLB : na_w + nb_w;  // copies this wave issues per tile
 #pragma unroll
   for (int p = 0; p < DEPTH; ++p)
     if (p < nt) issue(k_begin + p * BK, p);

@@ -5,6 +5,7 @@
 // on separate CUs); these kernels stream each weight a few times through one CU and are launch-count, not
 // bandwidth, optimisations: they replace ~6 tiny ATen kernels per conv per forward.
 #include "common.h"
+#include "x6.h"
 
 #define SN_MAX_ROWS 4096
 #define ENTRY_CHUNK 32
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(256) wp_unorm_kernel(const PrepArgs args) {
 __host__ __device__ inline int tr_cc(int taps) {
   int cc = TR_MAX / taps;
   if (cc > 32) cc = 32;
+  if (cc >= 8) cc &= ~7;  // whole groups of 8 channels per tile: a 16-byte chunk of the bf16 piece images never straddles two tiles
   return cc < 1 ? 1 : cc;
 }
 __host__ __device__ inline int64_t tr_tiles(int rows, int C, int taps) {
@@ -127,6 +129,37 @@ __global__ void __launch_bounds__(256) wp_pack_kernel(const PrepArgs args) {
     for (int i = threadIdx.x; i < rn * cn * taps; i += 256) {  // wt[tap][row][c]: cn consecutive channels per (tap, row)
       const int cl = i % cn, q = i / cn, rl = q % rn, tap = q / rn;
       e.wt[((int64_t)tap * rows + r0 + rl) * C + c0 + cl] = tile[rl][cl * taps + tap];
+    }
+  }
+  // bf16 piece images for the bf16x6 products (x6.h, ConvWX3 in gemm_core.h): one 16-byte chunk = 8 consecutive REDUCTION indices of one
+  // output column, three images (the exact three-way split of the fp32 value)
+  const int64_t pstride = (int64_t)taps * C * rows;
+  if (e.wf3 && (C & 7) == 0 && (cc & 7) == 0) {  // wf3[piece][tap][C / 8][rows][8]: reduction = channels
+    const int ncg = cn >> 3;
+    for (int i = threadIdx.x; i < taps * ncg * rn; i += 256) {
+      const int rl = i % rn, q = i / rn, cg = q % ncg, tap = q / ncg;
+      uint32_t w[3][4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        split3_pair(tile[rl][(cg * 8 + 2 * h) * taps + tap], tile[rl][(cg * 8 + 2 * h + 1) * taps + tap], w[0][h], w[1][h], w[2][h]);
+      const int64_t chunk = ((int64_t)tap * (C >> 3) + (c0 >> 3) + cg) * rows + r0 + rl;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.wf3) + pc * pstride + chunk * 8) = make_uint4(w[pc][0], w[pc][1], w[pc][2], w[pc][3]);
+    }
+  }
+  if (e.wt3 && (rows & 7) == 0) {  // wt3[piece][tap][rows / 8][C][8]: reduction = rows
+    const int nrg = rn >> 3;
+    for (int i = threadIdx.x; i < taps * nrg * cn; i += 256) {
+      const int cl = i % cn, q = i / cn, rg = q % nrg, tap = q / nrg;
+      uint32_t w[3][4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        split3_pair(tile[rg * 8 + 2 * h][cl * taps + tap], tile[rg * 8 + 2 * h + 1][cl * taps + tap], w[0][h], w[1][h], w[2][h]);
+      const int64_t chunk = ((int64_t)tap * (rows >> 3) + (r0 >> 3) + rg) * C + c0 + cl;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.wt3) + pc * pstride + chunk * 8) = make_uint4(w[pc][0], w[pc][1], w[pc][2], w[pc][3]);
     }
   }
 }

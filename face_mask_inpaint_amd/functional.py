@@ -138,10 +138,14 @@ def eltwise(op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, p0: floa
     return y
 
 
-def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1) -> Tuple[ConvDesc, int, int]:
+def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1, w3=None) -> Tuple[ConvDesc, int, int]:
+    """w3: the bf16 piece images (PackedWeight.wf3 / .wt3) of the weight operand the call will be given, or None"""
     oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
     ow = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
-    return ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode, dil), oh, ow
+    d = ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode, dil)
+    if w3 is not None:
+        d.w3 = w3.data_ptr()
+    return d, oh, ow
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -150,10 +154,15 @@ def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=No
 class PackedWeight:
     """Per-call packed effective weight of one conv: wf [taps][C][K] (autograd tensor), wt [taps][K][C]."""
 
-    __slots__ = ("wf", "wt", "rows", "C", "kh", "kw")
+    __slots__ = ("wf", "wt", "rows", "C", "kh", "kw", "w3")
 
-    def __init__(self, wf, wt, rows, Cc, kh, kw):
+    def __init__(self, wf, wt, rows, Cc, kh, kw, w3=(None, None)):
         self.wf, self.wt, self.rows, self.C, self.kh, self.kw = wf, wt, rows, Cc, kh, kw
+        self.w3 = w3  # (wf3, wt3): the same two packs as bf16 piece images (fmi_conv_desc.w3), or None where the shape has none
+
+
+W3_ENABLED = True  # write the bf16 piece images of every eligible pack (False: the kernels split the weight fragments themselves)
+_LAST_W3: List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]] = []
 
 
 class _WeightPrepare(torch.autograd.Function):
@@ -167,7 +176,7 @@ class _WeightPrepare(torch.autograd.Function):
         dev = ws[0].device
         sig = torch.ones(n, device=dev, dtype=torch.float32)
         entries = (_lib.WeightEntry * n)()
-        wfs, wts = [], []
+        wfs, wts, w3s = [], [], []
         for i, (w, (u, v)) in enumerate(zip(ws, metas)):
             _chk(w, u, v)
             rows, cc, kh, kw = w.shape
@@ -175,7 +184,13 @@ class _WeightPrepare(torch.autograd.Function):
                 raise FmiError("spectral-norm weight with more than 4096 rows")
             wf = torch.empty((kh * kw, cc, rows), device=dev, dtype=torch.float32)
             wt = torch.empty((kh * kw, rows, cc), device=dev, dtype=torch.float32)
+            pieces = W3_ENABLED and kh * kw <= 36 and w.is_cuda
+            wf3 = torch.empty(3 * kh * kw * cc * rows, device=dev, dtype=torch.bfloat16) if pieces and cc % 16 == 0 else None
+            wt3 = torch.empty(3 * kh * kw * cc * rows, device=dev, dtype=torch.bfloat16) if pieces and rows % 16 == 0 else None
+            w3s.append((wf3, wt3))
             e = entries[i]
+            e.wf3 = wf3.data_ptr() if wf3 is not None else None
+            e.wt3 = wt3.data_ptr() if wt3 is not None else None
             e.w = w.data_ptr()
             e.u = u.data_ptr() if u is not None else None
             e.v = v.data_ptr() if v is not None else None
@@ -186,6 +201,7 @@ class _WeightPrepare(torch.autograd.Function):
             wts.append(wt)
         lib.weight_prepare_f32(entries, n, _st())
         ctx.metas, ctx.ws, ctx.sig = metas, ws, sig
+        _LAST_W3[:] = w3s  # handed to prepare_weights (plain tensors next to the autograd outputs)
         ctx.mark_non_differentiable(sig, *wts)
         ctx.set_materialize_grads(False)  # packs that received no gradient arrive as None, not as freshly zero-filled tensors
         return (sig,) + tuple(wfs) + tuple(wts)
@@ -228,7 +244,9 @@ def prepare_weights(items: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], 
     ws = tuple(w for w, _, _ in items)
     n = len(ws)
     res = _WeightPrepare.apply(metas, *ws)
-    return [PackedWeight(res[1 + i], res[1 + n + i], w.shape[0], w.shape[1], w.shape[2], w.shape[3]) for i, w in enumerate(ws)]
+    w3s = list(_LAST_W3)
+    _LAST_W3.clear()
+    return [PackedWeight(res[1 + i], res[1 + n + i], w.shape[0], w.shape[1], w.shape[2], w.shape[3], w3s[i]) for i, w in enumerate(ws)]
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -246,7 +264,7 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv(x, W) + bias + residual); x [N,H,W,C], wf [taps][C][K]."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False, dil=1, passthrough=False):
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, pad_mode, act, in_act=None, skip_act_bwd=False, dil=1, passthrough=False, w3=(None, None)):
         """in_act: None, ("apply", slope): the convolution reads lrelu(x, slope) (computed here, and only IT is kept for the backward),
         ("mask", slope): x already is the output of such an activation; either way the input gradient is multiplied by act'(x) in the
         adjoint's epilogue.  skip_act_bwd: this convolution's own fused activation (act) is differentiated by its single consumer (a
@@ -258,7 +276,8 @@ class _Conv2d(torch.autograd.Function):
             x = eltwise(EW_LRELU, x, None, in_act[1])
         n, h, w, c = x.shape
         k = wf.shape[2]
-        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
+        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil, w3=w3[0])
+        ctx.wt3 = w3[1]
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}" + (f"d{dil}" if dil > 1 else ""), 2.0 * n * oh * ow * k * c * kh * kw):
             lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
@@ -276,7 +295,7 @@ class _Conv2d(torch.autograd.Function):
         lib = _L()
         x, wf, y = ctx.saved_tensors
         if gy is None:
-            return (gpass,) + (None,) * 15
+            return (gpass,) + (None,) * 16
         kh, kw, stride, pad, pad_mode, act = ctx.cfg
         gy = gy.contiguous()
         if act and not ctx.skip_act_bwd:
@@ -294,14 +313,14 @@ class _Conv2d(torch.autograd.Function):
                     lib.conv2d_thin_dgrad_f32(C.byref(d0), _p(gy), _p(ctx.wt), _p(gx), _st())
             elif pad_mode == 1:  # adjoint w.r.t. the reflection-padded tensor, then fold (base_function.py:390)
                 hp, wp = h + 2 * pad, w + 2 * pad
-                d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0)
+                d, _, _ = conv_desc(n, hp, wp, c, k, kh, kw, stride, 0, w3=ctx.wt3)
                 gpad = torch.empty((n, hp, wp, c), device=x.device, dtype=torch.float32)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     lib.conv2d_dgrad_f32(C.byref(d), _p(gy), _p(ctx.wt), None, None, _p(gpad), 1, 0, _st())
                 gx = torch.empty_like(x)
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
-                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil)
+                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil, w3=ctx.wt3)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     if ctx.in_slope is not None and gpass is not None:  # act'(x) in the epilogue, then + the other consumer's gradient
@@ -335,7 +354,7 @@ class _Conv2d(torch.autograd.Function):
             lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
-        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None, None
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _ThinConvLReLU(torch.autograd.Function):
@@ -401,7 +420,7 @@ def conv2d(x, pw: PackedWeight, bias=None, residual=None, stride=1, pad=0, pad_m
         if bias is not None or residual is not None or pad_mode or act or in_act is not None or dilation != 1:
             raise FmiError("the bf16 convolution has no bias / residual / activation / reflect-padding / dilation form")
         return _Conv2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad)
-    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd, int(dilation), bool(passthrough))
+    return _Conv2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, pad_mode, act, in_act, skip_act_bwd, int(dilation), bool(passthrough), pw.w3)
 
 
 # ---- bf16 activations (StyleGAN2 decoder of configs C3 / C5): fp32 master weights, bf16 copies packed per call ----
@@ -574,14 +593,15 @@ class _ConvTranspose2d(torch.autograd.Function):
     x [N,h,w,Cs]; packed weights are those of the conv view (rows = Cs, C = Cb)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, out_pad):
+    def forward(ctx, x, wf, bias, residual, wt, kh, kw, stride, pad, out_pad, w3=(None, None)):
         _chk(x, wf, bias, residual)
         lib = _L()
         n, h, w, cs = x.shape
         cb = wf.shape[1]
         H = (h - 1) * stride - 2 * pad + kh + out_pad
         W = (w - 1) * stride - 2 * pad + kw + out_pad
-        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=w3[1])
+        ctx.wf3 = w3[0]
         if (oh, ow) != (h, w):
             raise FmiError("unsupported ConvTranspose2d geometry")
         y = torch.empty((n, H, W, cb), device=x.device, dtype=torch.float32)
@@ -600,7 +620,7 @@ class _ConvTranspose2d(torch.autograd.Function):
         gy = gy.contiguous()
         n, h, w, cs = x.shape
         cb = wf.shape[1]
-        d, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad)
+        d, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=ctx.wf3)
         gx = gwf = gb = gres = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
@@ -614,7 +634,7 @@ class _ConvTranspose2d(torch.autograd.Function):
             gb = _bias_grad_of(gy, cb)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
-        return gx, gwf, gb, gres, None, None, None, None, None, None
+        return gx, gwf, gb, gres, None, None, None, None, None, None, None
 
 
 def conv_transpose2d(x, pw: PackedWeight, bias=None, residual=None, stride=2, pad=1, out_pad=1):
@@ -622,7 +642,7 @@ def conv_transpose2d(x, pw: PackedWeight, bias=None, residual=None, stride=2, pa
         if bias is not None or residual is not None:
             raise FmiError("the bf16 ConvTranspose2d has no bias / residual epilogue")
         return _ConvTranspose2dBF16.apply(x, pw.wf, pw.wt, pw.kh, pw.kw, stride, pad, out_pad)
-    return _ConvTranspose2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, out_pad)
+    return _ConvTranspose2d.apply(x, pw.wf, bias, residual, pw.wt, pw.kh, pw.kw, stride, pad, out_pad, pw.w3)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -76,6 +76,10 @@ typedef struct {
   int kh, kw, stride, pad;
   int pad_mode;      /* 0 = zeros, 1 = reflect (nn.ReflectionPad2d, base_function.py:390) */
   int dil;           /* dilation (modules/drn.py: 2 / 4 in the dilated stages); 0 or 1 = none.  fp32 family only, stride 1 for the adjoint */
+  const void* w3;    /* optional (NULL = none): the weight operand of THIS call -- wf for fwd, wt for dgrad -- once more as the three bf16
+                        piece images fmi_weight_prepare_f32 writes (entry.wf3 / entry.wt3).  fp32 products run as six bf16 MFMAs on exact
+                        three-way splits of both operands; with the pieces at hand only the activations are split inside the kernel.
+                        Results do not depend on whether it is given. */
 } fmi_conv_desc;
 
 /* y = conv(x, wf) + bias[k] + residual ; bias/residual may be NULL.
@@ -196,6 +200,8 @@ typedef struct {
   float* wt;        /* out [taps][rows][C] (may be NULL) */
   float* sigma;     /* out [1] (may be NULL when u == NULL) */
   int rows, C, taps, pad_;
+  void* wf3;        /* out, optional: wf as three bf16 piece images [3][taps][C/8][rows][8] (C % 8 == 0, taps <= 36), see fmi_conv_desc.w3 */
+  void* wt3;        /* out, optional: wt as three bf16 piece images [3][taps][rows/8][C][8] (rows % 8 == 0, taps <= 36) */
 } fmi_weight_entry;
 /* entries: HOST array (pointers inside are device pointers); passed to the kernels by value, <= 32 per launch */
 int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count, void* stream);

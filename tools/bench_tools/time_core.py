@@ -26,6 +26,12 @@ for (n, h, ci, co, k) in SHAPES:
     d, oh, ow = FF.conv_desc(n, h, h, ci, co, k, k, 1, k // 2)
     y = torch.empty(n, oh, ow, co, device=dev)
     convs.append((d, x, w, y, 2.0 * n * oh * ow * ci * co * k * k))
+    if os.environ.get("W3"):  # the bf16 piece images of the weights: [3][taps][C/8][K][8]
+        x0 = w.bfloat16(); r1 = w - x0.float(); x1 = r1.bfloat16(); x2 = (r1 - x1.float()).bfloat16()
+        w3 = torch.stack([t.view(k * k, ci // 8, 8, co).permute(0, 1, 3, 2).contiguous() for t in (x0, x1, x2)])
+        d.w3 = w3.data_ptr()
+        keep = globals().setdefault("_keep", [])
+        keep.append(w3)
 a2 = torch.randn(131072, 2304, device=dev); b2 = torch.randn(2304, 256, device=dev); c2 = torch.empty(131072, 256, device=dev)
 rounds = int(os.environ.get("ROUNDS", "2"))
 res = {}
