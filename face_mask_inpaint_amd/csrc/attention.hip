@@ -23,9 +23,7 @@
 #ifndef FMI_BWD_HOIST
 #define FMI_BWD_HOIST 0  // V k-steps whose three bf16 pieces the optimiser may keep in registers across query tiles (12 registers each)
 #endif
-#ifndef FMI_BWD_EXP
-#define FMI_BWD_EXP 0  // timing experiments on the x6 backward (wrong results): 1 no query-side product, 2 one dV tile, 4 one dP step, 8 no dS^T stores
-#endif
+
 
 template <int D, int CT, int NKL, int NVL, int NTH>
 __device__ __forceinline__ void att_gload(float4 (&rk)[NKL], float4 (&rv)[NVL], const float* __restrict__ qb,
@@ -832,14 +830,18 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   constexpr int GP = 2 * CT, GIMG = 32 * GP;   // gO piece image: row pitch, bytes per piece
   constexpr int QP = 192, QIMG = 32 * QP;      // Q piece image
   constexpr int TIMG = 32 * 64;                // dS^T piece image: [32 keys][32 q] bf16
+  constexpr int KP = 2 * D + 16, KIMG = 32 * KP;  // key-block piece image: row pitch (conflict-free row reads), bytes per piece
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* Gs = smem_b;                                     // [3][32][GP]
   unsigned char* Qs = Gs + 3 * GIMG;                              // [3][32][QP]
   float* lse_i = reinterpret_cast<float*>(Qs + 3 * QIMG);         // [32]
   float* del_i = lse_i + 32;                                      // [32]
-  float* Kw = del_i + 32;                                         // [4][32][LDQ]  each wave's key block, fp32 (B operand of dQ = dS K)
-  unsigned char* Ts = reinterpret_cast<unsigned char*>(Kw + 4 * 32 * LDQ);  // [4][3][32][64 B]  private transposed dS pieces
-  float* RB = reinterpret_cast<float*>(Ts + 4 * 3 * TIMG);        // [4][NDT][16][64]  query-side partial tiles of the four key blocks (LDS float atomics cost ~250 cycles per wave instruction: measured)
+  unsigned char* Ks = reinterpret_cast<unsigned char*>(del_i + 32);  // [4][3][32][KP]  each wave's key block as bf16 pieces: B operand of S (row reads) and of dQ = dS K (transposed reads)
+  unsigned char* Ts = Ks + 4 * 3 * KIMG;                          // [4][WSLOT]  per wave: the transposed dS pieces [3][32][64 B], then (same bytes) its query-side partial tiles
+  // a wave's partial dQ tiles [NDT][16][64] overwrite its own dS^T image once its transposed reads are done; the other waves read them between
+  // the two barriers that follow, and the image is rewritten only after the second one.  (LDS float atomics instead of partial tiles: ~250
+  // cycles per wave instruction, measured.)
+  constexpr int WSLOT = (NDT * 16 * 64 * 4 > 3 * TIMG) ? NDT * 16 * 64 * 4 : 3 * TIMG;
   typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem_b;
 
@@ -853,14 +855,19 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   const float* lseb = lse + (int64_t)n * T;
   const float* delb = delta + (int64_t)n * T;
 
-  float* kw = Kw + wid * 32 * LDQ;
+  unsigned char* ks = Ks + wid * 3 * KIMG;
   for (int f = lane; f < 8 * D; f += 64) {
-    const int key = f / (D / 4), dd = (f % (D / 4)) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(qb + (int64_t)(j0 + key) * D + dd);
-    float* d = kw + key * LDQ + dd;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    const int key = f / (D / 4), dq4 = f % (D / 4);
+    const float4 v = *reinterpret_cast<const float4*>(qb + (int64_t)(j0 + key) * D + dq4 * 4);
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split3_pair(v.x, v.y, a0, a1, a2);
+    split3_pair(v.z, v.w, b0, b1, b2);
+    unsigned char* d = ks + key * KP + dq4 * 8;
+    *reinterpret_cast<uint2*>(d) = make_uint2(a0, b0);
+    *reinterpret_cast<uint2*>(d + KIMG) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(d + 2 * KIMG) = make_uint2(a2, b2);
   }
-  // B fragments of this wave's keys, V[key = l31][16 kk + 8 lh + j], in registers (the K fragments are read from Kw per tile)
+  // B fragments of this wave's keys, V[key = l31][16 kk + 8 lh + j], in registers (the K fragments are read from the piece image per tile)
   float vfrag[CT / 16][8];
 #pragma unroll
   for (int kk = 0; kk < CT / 16; ++kk) {
@@ -955,7 +962,11 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   const int g_tx = (2 * gb + (tp >> 1)) ^ ((tq << 2) | lh);            // chunk 4 ct + 2 gb + (tp >> 1), swizzle of that row ((+8: ^ 2)
   const uint32_t q_row = lds0 + (uint32_t)(3 * GIMG + l31 * QP + 16 * lh);
   const uint32_t q_tr = lds0 + (uint32_t)(3 * GIMG + (4 * lh + tq) * QP + (16 * gb + 4 * tp) * 2);
-  const uint32_t t_base = (uint32_t)((unsigned char*)Ts - smem_b) + (uint32_t)(wid * 3 * TIMG);
+  const uint32_t k_base = lds0 + (uint32_t)(Ks - smem_b) + (uint32_t)(wid * 3 * KIMG);
+  const uint32_t k_row = k_base + (uint32_t)(l31 * KP + 16 * lh);                              // row fragments: key l31, + piece, + 32 kk
+  const uint32_t k_tr = k_base + (uint32_t)((8 * lh + tq) * KP + (16 * gb + 4 * tp) * 2);      // transposed: key rows 16 s + 8 lh + tq (+ 4), + 64 c
+  const uint32_t t_base = (uint32_t)(Ts - smem_b) + (uint32_t)(wid * WSLOT);
+  float* RBw = reinterpret_cast<float*>(Ts + wid * WSLOT);
   // dS^T image: row = key (64 bytes = 8 slots of four queries); slot (2 g + lh) of key k is stored at slot ^ ((k >> 1) & 7): the 16 keys
   // one ds_write_b64 group covers then fall on 16 different bank pairs (unswizzled: two)
   const uint32_t t_wr = lds0 + t_base + (uint32_t)(l31 * 64);                    // + piece, + 8 * ((2 g + lh) ^ t_wx)
@@ -979,10 +990,8 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
       bf16x8_t a[3], b[3];
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(q_row + (uint32_t)(pc * QIMG + kk * 32));
-      float kf[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kf[j] = kw[l31 * LDQ + 16 * kk + 8 * lh + j];
-      split3_bf16(kf, b);
+      for (int pc = 0; pc < 3; ++pc) b[pc] = *(lp8)(uintptr_t)(k_row + (uint32_t)(pc * KIMG + kk * 32));
       sp = mfma_x6(a, b, sp);
     }
     {  // software pipeline of depth one, fenced per step: the scheduler would otherwise hoist all 48 fragment reads (192 registers)
@@ -994,16 +1003,13 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
       bf16x8_t a[3], an[3], b[3];
       g_frag(0, a);
 #pragma unroll
-      for (int kk = 0; kk < ((FMI_BWD_EXP & 4) ? 1 : CT / 16); ++kk) {
+      for (int kk = 0; kk < CT / 16; ++kk) {
         if (kk + 1 < CT / 16) g_frag(kk + 1, an);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           if (kk >= FMI_BWD_HOIST) asm volatile("" : "+v"(vfrag[kk][j]));  // not loop-invariant for the optimiser: it would hoist all 192 piece registers out of the tile loop
         split3_bf16(vfrag[kk], b);
         dp = mfma_x6(a, b, dp);
-#ifdef FMI_ATT_FENCE
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
       }
@@ -1026,7 +1032,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
         split3_bf16(e, ds);
       }
 #pragma unroll
-      for (int pc = 0; pc < ((FMI_BWD_EXP & 8) ? 0 : 3); ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
+      for (int pc = 0; pc < 3; ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) u32x2_t* lpu2;
         const u32x4_t w = __builtin_bit_cast(u32x4_t, ds[pc]);
@@ -1044,12 +1050,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
         bf16x8_t a[3], an[3];
         gt_frag(0, a);
 #pragma unroll
-        for (int c = 0; c < ((FMI_BWD_EXP & 2) ? 1 : NCT); ++c) {
+        for (int c = 0; c < NCT; ++c) {
           if (c + 1 < NCT) gt_frag(c + 1, an);
           acc_dv[c] = mfma_x6(a, pp, acc_dv[c]);
-#ifdef FMI_ATT_FENCE
-          __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
         }
@@ -1063,19 +1066,15 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
         acc_dk[c] = mfma_x6(a, ds, acc_dk[c]);
       }
     }
-    bf16x8_t pp_dbg[3];
-    {
-      const float f[8] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], sp[6], sp[7]};
-      if (FMI_BWD_EXP & 64) split3_bf16(f, pp_dbg);
-    }
     // the next query tile's loads are issued only here: their 40 staging registers would otherwise be live across the dP / dV phases,
     // where the V fragments, the accumulators and the piece fragments already take the whole file (82 registers went to scratch)
     __builtin_amdgcn_sched_barrier(0);
     gload(i0 + 32 < T ? i0 + 32 : i0);
     // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed image was written by this wave; a wave's LDS operations complete in order
+    f32x16 dqs[NDT];
 #pragma unroll
-    for (int c = 0; c < ((FMI_BWD_EXP & 1) ? 0 : NDT); ++c) {
+    for (int c = 0; c < NDT; ++c) {
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -1084,36 +1083,30 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
         bf16x8_t a[3], b[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
-          if (FMI_BWD_EXP & 64) { a[pc] = pp_dbg[pc]; continue; }
           a[pc] = tr2(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
                       t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
         }
-        float kf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kf[j] = (FMI_BWD_EXP & 16) ? sp[j] : kw[(16 * s + 8 * lh + j) * LDQ + c * 32 + l31];
-        split3_bf16(kf, b);
+        for (int pc = 0; pc < 3; ++pc)
+          b[pc] = tr2(k_tr + (uint32_t)(pc * KIMG + 16 * s * KP + 64 * c), k_tr + (uint32_t)(pc * KIMG + (16 * s + 4) * KP + 64 * c));
         dq = mfma_x6(a, b, dq);
       }
-      float* rb = RB + ((wid * NDT + c) * 16) * 64 + lane;
-      if (FMI_BWD_EXP & 32) {
-        float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += dq[r];
-        if (t == 123.456f) rb[0] = t;
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) rb[r * 64] = dq[r];
+      dqs[c] = dq;
     }
-    __syncthreads();   // every wave is done with the query tile; RB holds the four partial dQ tiles
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's transposed reads of its dS^T image are done: the partial tiles may overwrite it
+#pragma unroll
+    for (int c = 0; c < NDT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) RBw[(c * 16 + r) * 64 + lane] = dqs[c][r];
+    __syncthreads();   // every wave is done with the query tile; the four slots hold the partial dQ tiles
     // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
 #pragma unroll
-    for (int rr = 0; rr < ((FMI_BWD_EXP & 33) ? 0 : NDT * 4); ++rr) {
+    for (int rr = 0; rr < NDT * 4; ++rr) {
       const int row = wid * NDT * 4 + rr;       // = c*16 + r
       const int c = row >> 4, r = row & 15;
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) sum += RB[((w * NDT + c) * 16 + r) * 64 + lane];
+      for (int w = 0; w < 4; ++w) sum += reinterpret_cast<const float*>(Ts + w * WSLOT)[(c * 16 + r) * 64 + lane];
       atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, sum);
     }
     lstore();
@@ -1178,7 +1171,7 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
 #if FMI_X6
 #define ATTB2_KERNEL attn_bwd2_x6_kernel
     auto lds2x = [](int d, int ct) {
-      return (size_t)(3 * 32 * 2 * ct + 3 * 32 * 192 + 64 * 4 + 4 * 32 * (d + 1) * 4 + 4 * 3 * 32 * 64 + 4 * (d / 32) * 16 * 64 * 4);
+      return (size_t)(3 * 32 * 2 * ct + 3 * 32 * 192 + 64 * 4 + 4 * 3 * 32 * (2 * d + 16) + 4 * ((d / 32) * 4096 > 6144 ? (d / 32) * 4096 : 6144));
     };
 #define ATTB2_LDS(DD, CC) lds2x(DD, CC)
 #else

@@ -224,7 +224,10 @@ static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, 
   const int N = a.Nout;
 #if FMI_X6
   static const bool w3_off = getenv("FMI_W3_OFF") != nullptr;  // debug A/B: split the weight fragments in registers as well
-  if (a.w3 && N > 32 && !w3_off) {  // 2 x 27 KB of LDS: two workgroups per CU (a 128-column piece tile would leave one)
+  // piece images of the weights: 2 x 27 KB of LDS at 64 columns (two workgroups per CU; a 128-column piece tile would leave one).  Measured
+  // at 8 x 128^2 256 -> 256 / 24 x 224^2 64 -> 64 / 8 x 32^2 128 -> 128: 163 / 154 / 81 TFLOP/s against 170 / 144 / 75 with both operands split in the
+  // consuming waves (128 x 128 tiles): taken for narrow outputs and for launches too small to fill the chip with the large tile
+  if (a.w3 && N > 32 && !w3_off && (N <= 64 || wgs(128, 128) < 800)) {
     C3_LAUNCH_(Tile128x64w, true);
     return fmi_launch_status();
   }
