@@ -643,3 +643,73 @@ def test_ranger_against_reference(dev, golden):
     assert set(opt.state[ps[0]]) == {"step", "exp_avg", "exp_avg_sq", "slow_buffer"} and opt.state[ps[0]]["step"] == 13
     with pytest.raises(ValueError):
         Ranger(ps, alpha=1.5)
+
+
+def _pieces_to_float(p3, taps, cred, nout):
+    """[3][taps][cred/8][nout][8] bf16 piece images -> three fp32 tensors [taps][cred][nout]"""
+    return [p3.view(3, taps, cred // 8, nout, 8)[i].permute(0, 1, 3, 2).reshape(taps, cred, nout).float() for i in range(3)]
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", [(2, 32, 64, 33, 31, 3, 1, 1), (2, 128, 128, 16, 16, 3, 1, 1), (1, 64, 256, 20, 20, 3, 1, 1), (2, 16, 48, 17, 15, 1, 1, 0),
+                                                      (3, 64, 32, 20, 20, 3, 2, 1), (2, 32, 64, 16, 16, 4, 2, 1), (2, 48, 80, 9, 11, 5, 1, 2)])
+def test_conv_weight_piece_images(dev, FF, n, c, k, h, w, ksz, stride, pad):
+    """fmi_weight_prepare_f32 also writes both packs as three bf16 piece images (fmi_conv_desc.w3): the pieces add up to the fp32 pack
+    EXACTLY (bf16x6 products lose nothing of the operands), sit in the [piece][tap][Cred/8][Nout][8] layout, and a convolution /
+    adjoint / ConvTranspose given the pieces returns what it returns when it splits the weight fragments itself."""
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(c * 7 + k)
+    wt_ = (torch.randn(k, c, ksz, ksz, generator=g) / (c * ksz * ksz) ** 0.5).to(dev)
+    wt_[0, 0, 0, 0] = 1.0e-20  # a tiny and a large value go through the split as well (exactness needs |x| >= 2^-100: the third piece is 2^-16 |x|)
+    wt_[1, 0, 0, 0] = 1.5e30
+    (pw,) = FF.prepare_weights([(wt_, None, None)])
+    taps = ksz * ksz
+    wf3, wt3 = pw.w3
+    assert (wf3 is not None) == (c % 16 == 0) and (wt3 is not None) == (k % 16 == 0)
+    for p3, pack_, cred, nout in ((wf3, pw.wf, c, k), (wt3, pw.wt, k, c)):
+        if p3 is None:
+            continue
+        x0, x1, x2 = _pieces_to_float(p3, taps, cred, nout)
+        assert torch.equal((x0.double() + x1.double() + x2.double()).float(), pack_.detach()), "pieces do not add up to the pack"
+        big = pack_.detach().abs() > 1e-30
+        assert float((x1.abs() / pack_.detach().abs().clamp_min(1e-38))[big].max()) <= 2.0 ** -8 and float((x2.abs() / pack_.detach().abs().clamp_min(1e-38))[big].max()) <= 2.0 ** -16
+    st = FF._st()
+    x = torch.randn(n, h, w, c, generator=g).to(dev)
+    outs = []
+    for w3 in (None, wf3):
+        d, oh, ow = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad, w3=w3)
+        y = torch.full((n, oh, ow, k), float("nan"), device=dev)
+        lib.conv2d_fwd_f32(C.byref(d), FF._p(x), FF._p(pw.wf.detach()), None, None, FF._p(y), 0, 1, 0, st)
+        outs.append(y)
+    assert torch.isfinite(outs[0][..., 2:]).all()
+    torch.testing.assert_close(outs[1][..., 2:], outs[0][..., 2:], rtol=2e-6, atol=2e-6 * float(outs[0][..., 2:].abs().max()))
+    gy = torch.randn(n, oh, ow, k, generator=g).to(dev)
+    gy[..., :2] = 0  # columns 0 / 1 carry the 1e-20 / 1.5e30 weights
+    outs = []
+    for w3 in (None, wt3):
+        d, _, _ = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad, w3=w3)
+        dx = torch.full((n, h, w, c), float("nan"), device=dev)
+        lib.conv2d_dgrad_f32(C.byref(d), FF._p(gy), FF._p(pw.wt), None, None, FF._p(dx), 1, 0, st)
+        outs.append(dx)
+    torch.testing.assert_close(outs[1], outs[0], rtol=2e-6, atol=2e-6 * float(outs[0].abs().max()))
+
+
+def test_bf16x6_product_accuracy(dev, FF):
+    """the fp32 GEMM on the bf16 matrix pipe (csrc/x6.h) against float64: error per element below 1e-6 of sum |a||b|, on average below
+    5e-8 (rocBLAS' fp32 GEMM on the same operands: 7e-7 / 3.4e-8; measured here 4.4e-7 / 2.9e-8), with rows spanning 1e-6 .. 1e6, and an
+    identity operand passing the other one through exactly"""
+    torch.manual_seed(0)
+    a = torch.randn(512, 1024, device=dev) * torch.exp(torch.randn(512, 1, device=dev) * 4)
+    b = torch.randn(1024, 384, device=dev) * torch.exp(torch.randn(1024, 1, device=dev))
+    c = torch.empty(512, 384, device=dev)
+    FF.gemm_raw(FF._p(a), FF._p(b), FF._p(c), 512, 384, 1024, (1024, 1), (384, 1), (384, 1))
+    ref = a.double() @ b.double()
+    den = a.double().abs() @ b.double().abs()
+    err = ((c.double() - ref).abs() / den)
+    assert float(err.max()) <= 1e-6 and float(err.mean()) <= 5e-8, (float(err.max()), float(err.mean()))
+    eye = torch.eye(256, device=dev)
+    m = torch.randn(256, 256, device=dev) * 1e3
+    out = torch.empty(256, 256, device=dev)
+    FF.gemm_raw(FF._p(eye), FF._p(m), FF._p(out), 256, 256, 256, (256, 1), (256, 1), (256, 1))
+    assert torch.equal(out, m)  # x = x0 + x1 + x2 exactly, and 1 * piece is exact in the fp32 accumulator
