@@ -20,9 +20,6 @@
 #include <cstdlib>
 
 #define ATT_THR 20.0f
-#ifndef FMI_BWD_HOIST
-#define FMI_BWD_HOIST 0  // V k-steps whose three bf16 pieces the optimiser may keep in registers across query tiles (12 registers each)
-#endif
 
 
 template <int D, int CT, int NKL, int NVL, int NTH>
@@ -819,14 +816,21 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
 //  * the query-side tiles of the four key blocks are summed in LDS (ds_add_f32) before the global atomics, as before.
 // Per query tile and wave: 264 bf16 MFMAs (8 448 matrix-pipe cycles; the fp32 kernel: 352 MFMAs, 22 528 cycles).
 // =====================================================================================================
-template <int D, int NCT>
+// DVLO, DVN: the value-channel tiles (32 channels each) whose dV this launch accumulates; FULL: also dP, dS, dK and both dQ terms.
+// With all 8 channel tiles in one launch the 128 dV + 32 dK accumulator registers leave no room for the V pieces (192 registers): V stays
+// fp32 and is split per tile (700 VALU instructions of ~2 400).  Two launches -- FULL with tiles 0..3, then a light one (S, P and dV of tiles
+// 4..7 only: no V, no dP, no atomics) -- cost 288 instead of 264 MFMAs per tile pair, but the first then holds 96 accumulator registers and
+// the optimiser keeps the V pieces across query tiles.
+template <int D, int NCT, int DVLO, int DVN, bool FULL>
 __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __restrict__ q, const float* __restrict__ v1,
                                                               const float* __restrict__ v2, const float* __restrict__ g1,
                                                               const float* __restrict__ g2, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, float* __restrict__ gv1,
                                                               float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
   constexpr int CT = NCT * 32, LDQ = D + 1, NDT = D / 32;
-  constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
+  constexpr int GLO = FULL ? 0 : DVLO * 32, GN = FULL ? CT : DVN * 32;   // gO channels staged per query tile
+  constexpr int HOIST_V = FULL && 2 * DVN <= NCT;                        // room for the V pieces in registers
+  constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * GN) / 256;
   constexpr int GP = 2 * CT, GIMG = 32 * GP;   // gO piece image: row pitch, bytes per piece
   constexpr int QP = 192, QIMG = 32 * QP;      // Q piece image
   constexpr int TIMG = 32 * 64;                // dS^T piece image: [32 keys][32 q] bf16
@@ -868,19 +872,21 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
     *reinterpret_cast<uint2*>(d + 2 * KIMG) = make_uint2(a2, b2);
   }
   // B fragments of this wave's keys, V[key = l31][16 kk + 8 lh + j], in registers (the K fragments are read from the piece image per tile)
-  float vfrag[CT / 16][8];
+  float vfrag[FULL ? CT / 16 : 1][8];
+  if constexpr (FULL) {
 #pragma unroll
-  for (int kk = 0; kk < CT / 16; ++kk) {
-    const int c = 16 * kk + 8 * lh;
-    const float* src = (c < C1) ? v1b + (int64_t)(j0 + l31) * C1 + c : v2b + (int64_t)(j0 + l31) * C2 + (c - C1);
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-    vfrag[kk][0] = a.x, vfrag[kk][1] = a.y, vfrag[kk][2] = a.z, vfrag[kk][3] = a.w;
-    vfrag[kk][4] = b.x, vfrag[kk][5] = b.y, vfrag[kk][6] = b.z, vfrag[kk][7] = b.w;
+    for (int kk = 0; kk < CT / 16; ++kk) {
+      const int c = 16 * kk + 8 * lh;
+      const float* src = (c < C1) ? v1b + (int64_t)(j0 + l31) * C1 + c : v2b + (int64_t)(j0 + l31) * C2 + (c - C1);
+      const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+      vfrag[kk][0] = a.x, vfrag[kk][1] = a.y, vfrag[kk][2] = a.z, vfrag[kk][3] = a.w;
+      vfrag[kk][4] = b.x, vfrag[kk][5] = b.y, vfrag[kk][6] = b.z, vfrag[kk][7] = b.w;
+    }
   }
 
-  f32x16 acc_dv[NCT], acc_dk[NDT];
+  f32x16 acc_dv[DVN], acc_dk[NDT];
 #pragma unroll
-  for (int c = 0; c < NCT; ++c)
+  for (int c = 0; c < DVN; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_dv[c][r] = 0.f;
 #pragma unroll
@@ -900,12 +906,12 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int f = tid + 256 * i;
-      const int row = f / (CT / 4), c = (f % (CT / 4)) * 4;
+      const int row = f / (GN / 4), c = GLO + (f % (GN / 4)) * 4;
       rg[i] = (c < C1) ? *reinterpret_cast<const float4*>(g1b + (int64_t)(i0 + row) * C1 + c)
                        : *reinterpret_cast<const float4*>(g2b + (int64_t)(i0 + row) * C2 + (c - C1));
     }
     rl = lseb[i0 + (tid & 31)];
-    rd = delb[i0 + (tid & 31)];
+    if constexpr (FULL) rd = delb[i0 + (tid & 31)];
   };
   auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
   auto lstore = [&]() {
@@ -925,7 +931,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < NVL; ++i) {
       const int f = tid + 256 * i;
-      const int row = f / (CT / 4), c4 = f % (CT / 4), ch = c4 >> 1;
+      const int row = f / (GN / 4), c4 = GLO / 4 + f % (GN / 4), ch = c4 >> 1;
       uint32_t a0, a1, a2, b0, b1, b2;
       split3_pair(rg[i].x, rg[i].y, a0, a1, a2);
       split3_pair(rg[i].z, rg[i].w, b0, b1, b2);
@@ -994,7 +1000,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
       for (int pc = 0; pc < 3; ++pc) b[pc] = *(lp8)(uintptr_t)(k_row + (uint32_t)(pc * KIMG + kk * 32));
       sp = mfma_x6(a, b, sp);
     }
-    {  // software pipeline of depth one, fenced per step: the scheduler would otherwise hoist all 48 fragment reads (192 registers)
+    if constexpr (FULL) {  // software pipeline of depth one: the fragment of step kk + 1 is read while step kk multiplies
       auto g_frag = [&](int kk, bf16x8_t (&a)[3]) {
         const uint32_t ad = g_row + (uint32_t)(16 * (((2 * kk) & 15) ^ g_rx) + 16 * ((2 * kk) & ~15));
 #pragma unroll
@@ -1005,9 +1011,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
 #pragma unroll
       for (int kk = 0; kk < CT / 16; ++kk) {
         if (kk + 1 < CT / 16) g_frag(kk + 1, an);
+        if constexpr (!HOIST_V) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (kk >= FMI_BWD_HOIST) asm volatile("" : "+v"(vfrag[kk][j]));  // not loop-invariant for the optimiser: it would hoist all 192 piece registers out of the tile loop
+          for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(vfrag[kk][j]));  // not loop-invariant for the optimiser: it would hoist all 192 piece registers out of the tile loop and spill
+        }
         split3_bf16(vfrag[kk], b);
         dp = mfma_x6(a, b, dp);
 #pragma unroll
@@ -1019,7 +1026,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
       const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float p = __expf(sp[r] - lse_i[qi]);
       sp[r] = p;
-      dp[r] = p * (dp[r] - del_i[qi]);
+      if constexpr (FULL) dp[r] = p * (dp[r] - del_i[qi]);
     }
     // ---- dV^T[c][key] += gO^T[c][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key];  dS pieces -> private transposed image
 #pragma unroll
@@ -1029,10 +1036,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
         const float f[8] = {sp[8 * s], sp[8 * s + 1], sp[8 * s + 2], sp[8 * s + 3], sp[8 * s + 4], sp[8 * s + 5], sp[8 * s + 6], sp[8 * s + 7]};
         split3_bf16(f, pp);
         const float e[8] = {dp[8 * s], dp[8 * s + 1], dp[8 * s + 2], dp[8 * s + 3], dp[8 * s + 4], dp[8 * s + 5], dp[8 * s + 6], dp[8 * s + 7]};
-        split3_bf16(e, ds);
+        if constexpr (FULL) split3_bf16(e, ds);
       }
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
+      for (int pc = 0; pc < (FULL ? 3 : 0); ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) u32x2_t* lpu2;
         const u32x4_t w = __builtin_bit_cast(u32x4_t, ds[pc]);
@@ -1048,17 +1055,17 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
             a[pc] = tr2(g_tr + (uint32_t)(pc * GIMG + 16 * s * GP) + ch0, g_tr + (uint32_t)(pc * GIMG + (16 * s + 8) * GP) + ch1);
         };
         bf16x8_t a[3], an[3];
-        gt_frag(0, a);
+        gt_frag(DVLO, a);
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (c + 1 < NCT) gt_frag(c + 1, an);
+        for (int c = 0; c < DVN; ++c) {
+          if (c + 1 < DVN) gt_frag(DVLO + c + 1, an);
           acc_dv[c] = mfma_x6(a, pp, acc_dv[c]);
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
         }
       }
 #pragma unroll
-      for (int c = 0; c < NDT; ++c) {
+      for (int c = 0; c < (FULL ? NDT : 0); ++c) {
         bf16x8_t a[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
@@ -1070,44 +1077,48 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
     // where the V fragments, the accumulators and the piece fragments already take the whole file (82 registers went to scratch)
     __builtin_amdgcn_sched_barrier(0);
     gload(i0 + 32 < T ? i0 + 32 : i0);
-    // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed image was written by this wave; a wave's LDS operations complete in order
-    f32x16 dqs[NDT];
-#pragma unroll
-    for (int c = 0; c < NDT; ++c) {
-      f32x16 dq;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8_t a[3], b[3];
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-          a[pc] = tr2(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
-                      t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
+    if constexpr (FULL) {
+      // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed image was written by this wave; a wave's LDS operations complete in order
+      f32x16 dqs[NDT];
+  #pragma unroll
+      for (int c = 0; c < NDT; ++c) {
+        f32x16 dq;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+  #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8_t a[3], b[3];
+  #pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            a[pc] = tr2(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
+                        t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
+          }
+  #pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            b[pc] = tr2(k_tr + (uint32_t)(pc * KIMG + 16 * s * KP + 64 * c), k_tr + (uint32_t)(pc * KIMG + (16 * s + 4) * KP + 64 * c));
+          dq = mfma_x6(a, b, dq);
         }
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          b[pc] = tr2(k_tr + (uint32_t)(pc * KIMG + 16 * s * KP + 64 * c), k_tr + (uint32_t)(pc * KIMG + (16 * s + 4) * KP + 64 * c));
-        dq = mfma_x6(a, b, dq);
+        dqs[c] = dq;
       }
-      dqs[c] = dq;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's transposed reads of its dS^T image are done: the partial tiles may overwrite it
-#pragma unroll
-    for (int c = 0; c < NDT; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) RBw[(c * 16 + r) * 64 + lane] = dqs[c][r];
-    __syncthreads();   // every wave is done with the query tile; the four slots hold the partial dQ tiles
-    // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
-#pragma unroll
-    for (int rr = 0; rr < NDT * 4; ++rr) {
-      const int row = wid * NDT * 4 + rr;       // = c*16 + r
-      const int c = row >> 4, r = row & 15;
-      float sum = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) sum += reinterpret_cast<const float*>(Ts + w * WSLOT)[(c * 16 + r) * 64 + lane];
-      atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, sum);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's transposed reads of its dS^T image are done: the partial tiles may overwrite it
+  #pragma unroll
+      for (int c = 0; c < NDT; ++c)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) RBw[(c * 16 + r) * 64 + lane] = dqs[c][r];
+      __syncthreads();   // every wave is done with the query tile; the four slots hold the partial dQ tiles
+      // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
+  #pragma unroll
+      for (int rr = 0; rr < NDT * 4; ++rr) {
+        const int row = wid * NDT * 4 + rr;       // = c*16 + r
+        const int c = row >> 4, r = row & 15;
+        float sum = 0.f;
+  #pragma unroll
+        for (int w = 0; w < 4; ++w) sum += reinterpret_cast<const float*>(Ts + w * WSLOT)[(c * 16 + r) * 64 + lane];
+        atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, sum);
+      }
+    } else {
+      __syncthreads();   // every wave is done with the query tile
     }
     lstore();
     __syncthreads();
@@ -1116,15 +1127,15 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   // ---- epilogue: dV rows of this wave's keys (plain stores) and the key-side dQ (atomics)
   const int64_t row = (int64_t)n * T + j0 + l31;
 #pragma unroll
-  for (int c = 0; c < NCT; ++c) {
-    const int ch = c * 32;
+  for (int c = 0; c < DVN; ++c) {
+    const int ch = (DVLO + c) * 32;
     float* ob = (ch < C1) ? gv1 + row * C1 + ch : gv2 + row * C2 + (ch - C1);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(ob + 8 * g + 4 * lh) = make_float4(acc_dv[c][4 * g], acc_dv[c][4 * g + 1], acc_dv[c][4 * g + 2], acc_dv[c][4 * g + 3]);
   }
 #pragma unroll
-  for (int c = 0; c < NDT; ++c) {
+  for (int c = 0; c < (FULL ? NDT : 0); ++c) {
     float* gqb = gq + row * D + c * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) atomicAdd(gqb + (r & 3) + 8 * (r >> 2) + 4 * lh, acc_dk[c][r]);
@@ -1168,26 +1179,43 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
     auto lds2 = [](int d, int ct) {
       return sizeof(float) * (size_t)(32 * (ct + 1) + 32 * (d + 1) + 64 + 4 * 32 * (d + 1) + 4 * 32 * 33 + 4 * (d / 32) * 16 * 64);
     };
-#if FMI_X6
-#define ATTB2_KERNEL attn_bwd2_x6_kernel
     auto lds2x = [](int d, int ct) {
       return (size_t)(3 * 32 * 2 * ct + 3 * 32 * 192 + 64 * 4 + 4 * 3 * 32 * (2 * d + 16) + 4 * ((d / 32) * 4096 > 6144 ? (d / 32) * 4096 : 6144));
     };
-#define ATTB2_LDS(DD, CC) lds2x(DD, CC)
-#else
-#define ATTB2_KERNEL attn_bwd2_kernel
-#define ATTB2_LDS(DD, CC) lds2(DD, CC)
-#endif
+    // two launches (dV of channel tiles 0..3 with everything else, then a light S / P / dV launch for tiles 4..7) let the first keep the V
+    // pieces in registers: measured 14.9 + 5.6 ms against 17.6 ms for the single launch -- off unless FMI_ATT_BWD_2PASS is set
+    static const bool one_pass = getenv("FMI_ATT_BWD_2PASS") == nullptr;
+#define ATTB2_X6(DD, NN, LO, CNT, FULLP)                                                                                 \
+  do {                                                                                                                   \
+    static bool attr_setx = false;                                                                                       \
+    if (!attr_setx) {                                                                                                    \
+      if (hipFuncSetAttribute((const void*)attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds2x(DD, NN * 32)) != hipSuccess)                                                    \
+        return FMI_ERR_LAUNCH;                                                                                           \
+      attr_setx = true;                                                                                                  \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>), grid2, block, lds2x(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
+                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+  } while (0)
 #define ATTB2_LAUNCH(DD, NN)                                                                                             \
   do {                                                                                                                   \
+    if (FMI_X6) {                                                                                                        \
+      if (NN == 8 && !one_pass) {                                                                                        \
+        ATTB2_X6(DD, NN, 0, NN / 2, true);                                                                               \
+        ATTB2_X6(DD, NN, NN / 2, NN / 2, false);                                                                         \
+      } else {                                                                                                           \
+        ATTB2_X6(DD, NN, 0, NN, true);                                                                                   \
+      }                                                                                                                  \
+      return fmi_launch_status();                                                                                        \
+    }                                                                                                                    \
     static bool attr_set2 = false;                                                                                       \
     if (!attr_set2) {                                                                                                    \
-      if (hipFuncSetAttribute((const void*)ATTB2_KERNEL<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,             \
-                              (int)ATTB2_LDS(DD, NN * 32)) != hipSuccess)                                                \
+      if (hipFuncSetAttribute((const void*)attn_bwd2_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                              (int)lds2(DD, NN * 32)) != hipSuccess)                                                     \
         return FMI_ERR_LAUNCH;                                                                                           \
       attr_set2 = true;                                                                                                  \
     }                                                                                                                    \
-    hipLaunchKernelGGL((ATTB2_KERNEL<DD, NN>), grid2, block, ATTB2_LDS(DD, NN * 32), st, q, v1, v2, go1, go2, lse,        \
+    hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse,         \
                        (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
     return fmi_launch_status();                                                                                          \
   } while (0)
@@ -1196,8 +1224,7 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
     if (D == 32 && nct == 4) ATTB2_LAUNCH(32, 4);
     if (D == 64 && nct == 4) ATTB2_LAUNCH(64, 4);
 #undef ATTB2_LAUNCH
-#undef ATTB2_KERNEL
-#undef ATTB2_LDS
+#undef ATTB2_X6
   }
   const dim3 grid(T / 32, N);
   auto lds_bytes = [](int d, int ct) { return sizeof(float) * (size_t)(2 * 32 * (ct + 1) + 2 * 32 * (d + 1) + 64 + 4 * 2 * 1024 + 2 * 32 * 33); };
