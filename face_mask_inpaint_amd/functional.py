@@ -170,21 +170,23 @@ class _WeightPrepare(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, metas, *ws):
-        # metas[i] = (u, v) parameters or (None, None); ws[i] = weight in torch layout [rows][C][kh][kw]
+        # metas[i] = (u, v[, want_w3]) parameters or (None, None); ws[i] = weight in torch layout [rows][C][kh][kw]
         lib = _L()
         n = len(ws)
         dev = ws[0].device
         sig = torch.ones(n, device=dev, dtype=torch.float32)
         entries = (_lib.WeightEntry * n)()
         wfs, wts, w3s = [], [], []
-        for i, (w, (u, v)) in enumerate(zip(ws, metas)):
+        for i, (w, meta) in enumerate(zip(ws, metas)):
+            u, v = meta[0], meta[1]
+            want_w3 = meta[2] if len(meta) > 2 else True
             _chk(w, u, v)
             rows, cc, kh, kw = w.shape
             if u is not None and rows > 4096:
                 raise FmiError("spectral-norm weight with more than 4096 rows")
             wf = torch.empty((kh * kw, cc, rows), device=dev, dtype=torch.float32)
             wt = torch.empty((kh * kw, rows, cc), device=dev, dtype=torch.float32)
-            pieces = W3_ENABLED and kh * kw <= 36 and w.is_cuda
+            pieces = W3_ENABLED and want_w3 and kh * kw <= 36 and w.is_cuda
             wf3 = torch.empty(3 * kh * kw * cc * rows, device=dev, dtype=torch.bfloat16) if pieces and cc % 16 == 0 else None
             wt3 = torch.empty(3 * kh * kw * cc * rows, device=dev, dtype=torch.bfloat16) if pieces and rows % 16 == 0 else None
             w3s.append((wf3, wt3))
@@ -218,7 +220,7 @@ class _WeightPrepare(torch.autograd.Function):
             keep = []
             for j, i in enumerate(live):
                 w = ctx.ws[i]
-                u, v = ctx.metas[i]
+                u, v = ctx.metas[i][0], ctx.metas[i][1]
                 g = gwf[i].contiguous()
                 dw = torch.empty_like(w)
                 keep.append(g)
@@ -238,10 +240,11 @@ class _WeightPrepare(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def prepare_weights(items: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]]) -> List[PackedWeight]:
-    """items: (weight[rows,C,kh,kw], u or None, v or None).  One launch; returns PackedWeight per item."""
-    metas = tuple((u, v) for _, u, v in items)
-    ws = tuple(w for w, _, _ in items)
+def prepare_weights(items: Sequence[tuple]) -> List[PackedWeight]:
+    """items: (weight[rows,C,kh,kw], u or None, v or None[, want_w3 = True]).  One launch; returns PackedWeight per item.  want_w3 = False:
+    no bf16 piece images for this weight (its convolution runs on bf16 activations, which has its own weight packs)."""
+    metas = tuple(tuple(it[1:]) for it in items)
+    ws = tuple(it[0] for it in items)
     n = len(ws)
     res = _WeightPrepare.apply(metas, *ws)
     w3s = list(_LAST_W3)

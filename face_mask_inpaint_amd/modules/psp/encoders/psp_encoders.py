@@ -74,6 +74,11 @@ class GradualStyleEncoder(Module):
         x = run_conv(self.input_layer[0], x)
         x = FF.prelu(batch_norm(self.input_layer[1], x), self.input_layer[2].weight)
         b16 = self.body_dtype == torch.bfloat16 and self.training
+        if getattr(self, "_fmi_body_b16", None) != b16:  # the body's convolutions need no fp32 piece images while they run on bf16 activations
+            for m in self.body.modules():
+                if isinstance(m, nn.Conv2d):
+                    object.__setattr__(m, "_fmi_no_w3", b16)
+            object.__setattr__(self, "_fmi_body_b16", b16)
         if b16:
             x = x.to(torch.bfloat16)
         taps = {}

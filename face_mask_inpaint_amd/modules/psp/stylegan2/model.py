@@ -122,11 +122,11 @@ class ModulatedConv2d(nn.Module):
         xs = FF.scale_channels(x, s)
         if self.upsample:
             # conv_transpose2d(stride 2, pad 0) = adjoint of the stride-2 conv whose weight is [I][O][k][k]
-            (pw,) = FF.prepare_weights([(w.transpose(0, 1).contiguous(), None, None)])
+            (pw,) = FF.prepare_weights([(w.transpose(0, 1).contiguous(), None, None, x.dtype == torch.float32)])
             out = FF.conv_transpose2d(xs, pw, None, None, stride=2, pad=0, out_pad=0)
             out = self.blur.nhwc(out)
         else:
-            (pw,) = FF.prepare_weights([(w, None, None)])
+            (pw,) = FF.prepare_weights([(w, None, None, x.dtype == torch.float32)])
             fuse = not self.demodulate
             out = FF.conv2d(xs, pw, bias if fuse else None, residual if fuse else None, 1, self.padding)
             if fuse:

@@ -64,10 +64,11 @@ class weight_scope:
             if convs:
                 items = []
                 for c in convs:
+                    w3 = not getattr(c, "_fmi_no_w3", False)  # set on convolutions that run on bf16 activations
                     if hasattr(c, "weight_bar"):
-                        items.append((c.weight_bar, c.weight_u, c.weight_v))
+                        items.append((c.weight_bar, c.weight_u, c.weight_v, w3))
                     else:
-                        items.append((c.weight, None, None))
+                        items.append((c.weight, None, None, w3))
                 for c, pw in zip(convs, FF.prepare_weights(items)):
                     object.__setattr__(c, "_fmi_packed", pw)
         _ACTIVE[0] += 1

