@@ -275,5 +275,7 @@ def test_train_step_captured_in_a_hip_graph_equals_eager(dev):
     for i, (a, b) in enumerate(zip(le, lg)):
         assert abs(a - b) <= (2e-3 if i < 2 else 1e-2) * abs(a), (le, lg)
     assert le[-1] != le[0]  # the optimiser really moved the weights
-    # Adam's update is lr * g / (|g| + eps)-like in the first steps: elements whose gradient is rounding noise may move by lr in either run
-    assert float((we - wg).abs().max()) <= 4 * 1e-4 + 1e-6
+    # Adam's update is lr * g / (|g| + eps)-like in the first steps: an element whose gradient is rounding noise moves by up to lr per step in
+    # EITHER direction in either run, so two runs can end 2 * steps * lr apart on such an element (observed 6.1e-4; almost all are below 1e-5)
+    dw = (we - wg).abs()
+    assert float(dw.max()) <= 2 * 4 * 1e-4 * 1.02 and float(dw.median()) <= 2e-5, (float(dw.max()), float(dw.median()))
