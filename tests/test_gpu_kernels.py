@@ -713,3 +713,30 @@ def test_bf16x6_product_accuracy(dev, FF):
     out = torch.empty(256, 256, device=dev)
     FF.gemm_raw(FF._p(eye), FF._p(m), FF._p(out), 256, 256, 256, (256, 1), (256, 1), (256, 1))
     assert torch.equal(out, m)  # x = x0 + x1 + x2 exactly, and 1 * piece is exact in the fp32 accumulator
+
+
+@pytest.mark.parametrize("n,t,d,cs", [(8, 2048, 64, (256,)), (8, 2048, 32, (128, 128)), (8, 2048, 32, (128,)), (8, 2048, 64, (64, 64)), (4, 4096, 64, (128, 128))])
+def test_fused_attention_backward_key_block_structure(dev, FF, n, t, d, cs):
+    """sizes at which fmi_attention_bwd_f32 takes the second structure ((T / 128) * N >= 128: attn_bwd2_x6_kernel, every instantiation):
+    dQ (query side + key side, fp32 atomics) and dV against float64 autograd of softmax(q q^T) v on the same device"""
+    g = torch.Generator().manual_seed(t + d + sum(cs))
+    q = (torch.randn(n, t, d, generator=g) * 0.5).to(dev)
+    vs = [torch.randn(n, t, c, generator=g).to(dev) for c in cs]
+    gos = [torch.randn(n, t, c, generator=g).to(dev) for c in cs]
+    q64 = q.double().requires_grad_(True)
+    v64 = [v.double().requires_grad_(True) for v in vs]
+    att = torch.softmax(q64 @ q64.transpose(1, 2), -1)
+    outs = [att @ v for v in v64]
+    torch.autograd.backward(outs, [go.double() for go in gos])
+    del att
+    qd = q.clone().requires_grad_(True)
+    vds = [v.clone().requires_grad_(True) for v in vs]
+    res = FF.self_attention(qd, vds)
+    for r, o in zip(res, outs):
+        torch.testing.assert_close(r.detach().double(), o.detach(), rtol=1e-4, atol=1e-5)
+    torch.autograd.backward(res, gos)
+    gq, gq64 = qd.grad.double(), q64.grad
+    scale = float(gq64.abs().max())
+    assert float((gq - gq64).abs().max()) <= 2e-5 * scale + 1e-6, (float((gq - gq64).abs().max()), scale)  # measured ~3e-6 of the largest entry
+    for vd, v in zip(vds, v64):
+        torch.testing.assert_close(vd.grad.double(), v.grad, rtol=1e-4, atol=2e-5)
