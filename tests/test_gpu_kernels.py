@@ -651,7 +651,9 @@ def _pieces_to_float(p3, taps, cred, nout):
 
 
 @pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", [(2, 32, 64, 33, 31, 3, 1, 1), (2, 128, 128, 16, 16, 3, 1, 1), (1, 64, 256, 20, 20, 3, 1, 1), (2, 16, 48, 17, 15, 1, 1, 0),
-                                                      (3, 64, 32, 20, 20, 3, 2, 1), (2, 32, 64, 16, 16, 4, 2, 1), (2, 48, 80, 9, 11, 5, 1, 2)])
+                                                      (3, 64, 32, 20, 20, 3, 2, 1), (2, 32, 64, 16, 16, 4, 2, 1), (2, 48, 80, 9, 11, 5, 1, 2),
+                                                      # deep reductions on small maps: the piece images under a split reduction (tap-reuse kernel, strided adjoint phases)
+                                                      (4, 512, 256, 8, 8, 3, 1, 1), (4, 512, 256, 8, 8, 3, 2, 1), (8, 512, 512, 2, 2, 3, 2, 1)])
 def test_conv_weight_piece_images(dev, FF, n, c, k, h, w, ksz, stride, pad):
     """fmi_weight_prepare_f32 also writes both packs as three bf16 piece images (fmi_conv_desc.w3): the pieces add up to the fp32 pack
     EXACTLY (bf16x6 products lose nothing of the operands), sit in the [piece][tap][Cred/8][Nout][8] layout, and a convolution /
