@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
 
 
 class WeightEntry(C.Structure):
-    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("wf", vp), ("wt", vp), ("sigma", vp), ("rows", i32), ("C", i32), ("taps", i32), ("pad_", i32), ("wf3", vp), ("wt3", vp)]
+    _fields_ = [("w", vp), ("u", vp), ("v", vp), ("wf", vp), ("wt", vp), ("sigma", vp), ("rows", i32), ("C", i32), ("taps", i32), ("iters", i32), ("wf3", vp), ("wt3", vp)]
 
 
 class WeightGradEntry(C.Structure):

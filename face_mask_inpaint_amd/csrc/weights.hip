@@ -9,7 +9,8 @@
 
 #define SN_MAX_ROWS 4096
 #define ENTRY_CHUNK 32
-struct PrepArgs { fmi_weight_entry e[ENTRY_CHUNK]; };
+struct PrepArgs { fmi_weight_entry e[ENTRY_CHUNK]; int it; };  // it: power iteration this launch belongs to (entries with fewer iterations sit it out)
+__host__ __device__ inline int sn_iters(const fmi_weight_entry& e) { return e.iters > 1 ? e.iters : 1; }
 struct GradArgs { fmi_weight_grad_entry e[ENTRY_CHUNK]; };
 struct AdamArgs { fmi_adam_entry e[ENTRY_CHUNK * 2]; };
 
@@ -21,7 +22,7 @@ struct AdamArgs { fmi_adam_entry e[ENTRY_CHUNK * 2]; };
 __global__ void __launch_bounds__(256) wp_wtu_kernel(const PrepArgs args) {
   __shared__ float su[SN_MAX_ROWS];
   const fmi_weight_entry e = args.e[blockIdx.y];
-  if (!e.u) return;
+  if (!e.u || args.it >= sn_iters(e)) return;
   const int width = e.C * e.taps, j0 = blockIdx.x * 256;
   if (j0 >= width) return;
   for (int i = threadIdx.x; i < e.rows; i += 256) su[i] = e.u[i];
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256) wp_wtu_kernel(const PrepArgs args) {
 __global__ void __launch_bounds__(256) wp_vnorm_kernel(const PrepArgs args) {
   __shared__ float red[4];
   const fmi_weight_entry e = args.e[blockIdx.x];
-  if (!e.u) return;
+  if (!e.u || args.it >= sn_iters(e)) return;
   const int width = e.C * e.taps;
   float n = 0.f;
   for (int j = threadIdx.x; j < width; j += 256) n += e.v[j] * e.v[j];
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) wp_vnorm_kernel(const PrepArgs args) {
 // stage 3: t[r] = W[r,:] . v  (one wave per row; written into u, whose old value is no longer needed)
 __global__ void __launch_bounds__(256) wp_wv_kernel(const PrepArgs args) {
   const fmi_weight_entry e = args.e[blockIdx.y];
-  if (!e.u) return;
+  if (!e.u || args.it >= sn_iters(e)) return;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= e.rows) return;
   const int width = e.C * e.taps;
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) wp_wv_kernel(const PrepArgs args) {
 __global__ void __launch_bounds__(256) wp_unorm_kernel(const PrepArgs args) {
   __shared__ float red[4];
   const fmi_weight_entry e = args.e[blockIdx.x];
-  if (!e.u) return;
+  if (!e.u || args.it >= sn_iters(e)) return;
   float n = 0.f;
   for (int i = threadIdx.x; i < e.rows; i += 256) n += e.u[i] * e.u[i];
   n = sqrtf(block_sum_256(n, red));
@@ -171,6 +172,7 @@ extern "C" int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count
     if (!e.w || !e.wf || e.rows <= 0 || e.C <= 0 || e.taps <= 0) return FMI_ERR_BAD_ARG;
     if (e.u && (!e.v || !e.sigma)) return FMI_ERR_BAD_ARG;
     if (e.u && e.rows > SN_MAX_ROWS) return FMI_ERR_UNSUPPORTED;
+    if (e.iters < 0 || e.iters > 64) return FMI_ERR_BAD_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += ENTRY_CHUNK) {
@@ -186,12 +188,16 @@ extern "C" int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count
       if ((int64_t)w * a.e[i].rows > max_t) max_t = (int64_t)w * a.e[i].rows;
       if (a.e[i].u) any_sn = 1;
     }
-    if (any_sn) {
+    int max_it = 0;
+    for (int i = 0; i < n; ++i)
+      if (a.e[i].u && sn_iters(a.e[i]) > max_it) max_it = sn_iters(a.e[i]);
+    for (a.it = 0; a.it < (any_sn ? max_it : 0); ++a.it) {  // external_function.py:36: for _ in range(power_iterations)
       hipLaunchKernelGGL(wp_wtu_kernel, dim3((max_w + 255) / 256, n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(wp_vnorm_kernel, dim3(n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(wp_wv_kernel, dim3((max_r + 3) / 4, n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(wp_unorm_kernel, dim3(n), dim3(256), 0, st, a);
     }
+    a.it = 0;
     int64_t max_tiles = 1;
     for (int i = 0; i < n; ++i) {
       const int64_t t = a.e[i].taps > TR_MAX ? 1024 : tr_tiles(a.e[i].rows, a.e[i].C, a.e[i].taps);

@@ -170,7 +170,7 @@ class _WeightPrepare(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, metas, *ws):
-        # metas[i] = (u, v[, want_w3]) parameters or (None, None); ws[i] = weight in torch layout [rows][C][kh][kw]
+        # metas[i] = (u, v[, want_w3[, power_iterations]]) parameters or (None, None); ws[i] = weight in torch layout [rows][C][kh][kw]
         lib = _L()
         n = len(ws)
         dev = ws[0].device
@@ -180,6 +180,7 @@ class _WeightPrepare(torch.autograd.Function):
         for i, (w, meta) in enumerate(zip(ws, metas)):
             u, v = meta[0], meta[1]
             want_w3 = meta[2] if len(meta) > 2 else True
+            iters = int(meta[3]) if len(meta) > 3 else 1
             _chk(w, u, v)
             rows, cc, kh, kw = w.shape
             if u is not None and rows > 4096:
@@ -198,7 +199,7 @@ class _WeightPrepare(torch.autograd.Function):
             e.v = v.data_ptr() if v is not None else None
             e.wf, e.wt = wf.data_ptr(), wt.data_ptr()
             e.sigma = sig.data_ptr() + 4 * i
-            e.rows, e.C, e.taps = rows, cc, kh * kw
+            e.rows, e.C, e.taps, e.iters = rows, cc, kh * kw, iters
             wfs.append(wf)
             wts.append(wt)
         lib.weight_prepare_f32(entries, n, _st())
@@ -241,8 +242,9 @@ class _WeightPrepare(torch.autograd.Function):
 
 
 def prepare_weights(items: Sequence[tuple]) -> List[PackedWeight]:
-    """items: (weight[rows,C,kh,kw], u or None, v or None[, want_w3 = True]).  One launch; returns PackedWeight per item.  want_w3 = False:
-    no bf16 piece images for this weight (its convolution runs on bf16 activations, which has its own weight packs)."""
+    """items: (weight[rows,C,kh,kw], u or None, v or None[, want_w3 = True[, power_iterations = 1]]).  One launch sequence; returns
+    PackedWeight per item.  want_w3 = False: no bf16 piece images for this weight (its convolution runs on bf16 activations, which has
+    its own weight packs)."""
     metas = tuple(tuple(it[1:]) for it in items)
     ws = tuple(it[0] for it in items)
     n = len(ws)

@@ -25,13 +25,14 @@ class SpectralNorm(nn.Module):
 
     def __init__(self, module, name="weight", power_iterations=1):
         super().__init__()
-        if power_iterations != 1:
-            raise NotImplementedError("the HIP weight-preparation kernel runs one power iteration, as every caller in the reference does")
+        if not 1 <= int(power_iterations) <= 64:
+            raise ValueError("power_iterations must be in 1 .. 64")
         if name != "weight" or not isinstance(module, (nn.Conv2d, nn.ConvTranspose2d)):
             raise NotImplementedError("SpectralNorm wraps the 'weight' of Conv2d / ConvTranspose2d only")
         self.module = module
         self.name = name
         self.power_iterations = power_iterations
+        object.__setattr__(module, "_fmi_power_iterations", int(power_iterations))  # read by weights.weight_scope
         if not hasattr(module, name + "_bar"):
             w = getattr(module, name)
             height = w.data.shape[0]

@@ -66,7 +66,7 @@ class weight_scope:
                 for c in convs:
                     w3 = not getattr(c, "_fmi_no_w3", False)  # set on convolutions that run on bf16 activations
                     if hasattr(c, "weight_bar"):
-                        items.append((c.weight_bar, c.weight_u, c.weight_v, w3))
+                        items.append((c.weight_bar, c.weight_u, c.weight_v, w3, getattr(c, "_fmi_power_iterations", 1)))
                     else:
                         items.append((c.weight, None, None, w3))
                 for c, pw in zip(convs, FF.prepare_weights(items)):

@@ -189,7 +189,7 @@ int fmi_reflect_pad_fold_f32(const float* gpad, float* gx, int N, int H, int W, 
  * One launch handles a whole network: entry i describes one conv weight in the
  * torch layout w[rows][C*taps] (rows = K for Conv2d, = in_channels for
  * ConvTranspose2d, which is also the conv-view K).
- * If u != NULL: v <- normalize(W^T u); u <- normalize(W v); sigma = u.(W v);
+ * If u != NULL: `iters` times { v <- normalize(W^T u); u <- normalize(W v) }; sigma = u.(W v);
  * the packed copies hold W / sigma.  If u == NULL the packed copies hold W.
  * ---------------------------------------------------------------------- */
 typedef struct {
@@ -199,7 +199,8 @@ typedef struct {
   float* wf;        /* out [taps][C][rows] */
   float* wt;        /* out [taps][rows][C] (may be NULL) */
   float* sigma;     /* out [1] (may be NULL when u == NULL) */
-  int rows, C, taps, pad_;
+  int rows, C, taps;
+  int iters;        /* power iterations of the spectral norm (external_function.py:22,36); 0 or 1 = one, as every caller in the reference */
   void* wf3;        /* out, optional: wf as three bf16 piece images [3][taps][C/8][rows][8] (C % 8 == 0, taps <= 36), see fmi_conv_desc.w3 */
   void* wt3;        /* out, optional: wt as three bf16 piece images [3][taps][rows/8][C][8] (rows % 8 == 0, taps <= 36) */
 } fmi_weight_entry;

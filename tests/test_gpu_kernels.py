@@ -210,6 +210,46 @@ def test_spectral_norm_prepare_and_grad(dev, FF):
         torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-5)
 
 
+def test_spectral_norm_power_iterations(dev, FF):
+    """SpectralNorm(power_iterations = k) (external_function.py:22,36: the loop runs k times per forward; every caller in the reference uses 1):
+    one weight-preparation call with entries of different k, against the loop written out"""
+    from face_mask_inpaint_amd.modules.pluralistic_model.external_function import SpectralNorm
+
+    g = torch.Generator().manual_seed(12)
+    items, refs = [], []
+    for shape, k in (((16, 8, 3, 3), 3), ((32, 16, 1, 1), 1), ((24, 32, 3, 3), 5)):
+        w = torch.randn(*shape, generator=g)
+        h = shape[0]
+        u = F.normalize(torch.randn(h, generator=g), dim=0)
+        v = F.normalize(torch.randn(w[0].numel(), generator=g), dim=0)
+        wm = w.reshape(h, -1)
+        ur, vr = u.clone(), v.clone()
+        for _ in range(k):
+            vr = wm.t().mv(ur)
+            vr = vr / (vr.norm() + 1e-12)
+            ur = wm.mv(vr)
+            ur = ur / (ur.norm() + 1e-12)
+        refs.append((ur, vr, w / ur.dot(wm.mv(vr))))
+        items.append((w.to(dev), u.to(dev), v.to(dev), True, k))
+    for pw, it, (ur, vr, weff) in zip(FF.prepare_weights(items), items, refs):
+        torch.testing.assert_close(it[1].cpu(), ur, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(it[2].cpu(), vr, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pw.wf.detach().cpu(), pack(weff)[0], rtol=1e-5, atol=1e-6)
+    sn = SpectralNorm(torch.nn.Conv2d(8, 16, 3, padding=1), power_iterations=2).to(dev)
+    w0, u0, v0 = sn.module.weight_bar.detach().clone(), sn.module.weight_u.detach().clone(), sn.module.weight_v.detach().clone()
+    x = torch.randn(2, 8, 9, 7, generator=g).to(dev)
+    y = sn(x)
+    wm = w0.reshape(16, -1)
+    for _ in range(2):
+        v0 = wm.t().mv(u0)
+        v0 = v0 / (v0.norm() + 1e-12)
+        u0 = wm.mv(v0)
+        u0 = u0 / (u0.norm() + 1e-12)
+    ref = F.conv2d(x, w0 / u0.dot(wm.mv(v0)), sn.module.bias, padding=1)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sn.module.weight_u.detach(), u0, rtol=1e-5, atol=1e-6)
+
+
 def test_eltwise_and_softplus(dev, FF):
     g = torch.Generator().manual_seed(3)
     a = torch.randn(3, 5, 7, 9, generator=g) * 3
