@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a, float* __re
 // =====================================================================================
 // Matrix-core forms: v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer products per instruction; lane l = 4*blk + i
 // supplies A_blk[i] and B_blk[i], and register r of lane 4*blk + i accumulates A_blk[r] * B_blk[i] (layout probed on gfx950:
-// scripts/exp/probe_mfma4.hip) -- so the per-lane quantity (a pixel, a channel) goes on B and the 4-wide one (output channels) on A.  A block is one (pixel group, 4-channel chunk) pair: with C = 32 the 16 blocks
+// tools/bench_tools/probe_mfma4.hip) -- so the per-lane quantity (a pixel, a channel) goes on B and the 4-wide one (output channels) on A.  A block is one (pixel group, 4-channel chunk) pair: with C = 32 the 16 blocks
 // are 8 chunks x 2 pixel groups, lane = ((g * CQ + q) * 4 + i).  One instruction replaces 4 x K scalar FMAs per lane, the
 // operand loads stay the coalesced 16-byte (forward) / 4-byte (gradients) gathers of the scalar kernels above.
 // =====================================================================================
