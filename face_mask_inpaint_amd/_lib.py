@@ -18,7 +18,7 @@ i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 class ConvDesc(C.Structure):
     """fmi_conv_desc (include/fmi_hip.h)."""
 
-    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode", "dil")] + [("w3", C.c_void_p)]
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "OH", "OW", "K", "x_cstride", "y_cstride", "kh", "kw", "stride", "pad", "pad_mode", "dil")] + [("w3", C.c_void_p), ("x3", C.c_void_p), ("y3", C.c_void_p)]
 
 
 class WeightEntry(C.Structure):
@@ -42,6 +42,8 @@ PD = C.POINTER(ConvDesc)
 # name -> argtypes (return type is always int status unless noted)
 SIGNATURES = {
     "fmi_gemm_f32": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64, i64, f32, f32, vp, vp],
+    "fmi_split3_f32": [vp, vp, vp, i64, i32, i32, f32, vp],
+    "fmi_merge3_f32": [vp, vp, i64, i32, vp],
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],
     "fmi_conv2d_dgrad_masked_f32": [PD, vp, vp, vp, f32, vp, vp],

@@ -2,6 +2,7 @@
 // and weight gradient.  See include/fmi_hip.h for the contract and gemm_core.h for the machine mapping.
 #include "gemm_core.h"
 #include "conv3x3.h"
+#include "conv_p3.h"
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool ep_scalar() {  // debug: FMI_EP_SCALAR = never use the 16-byte epilogue (read once)
@@ -85,9 +86,10 @@ static int conv_ksplit(int64_t M, int N, int K) {
 #endif
 }
 
-extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
-                                  const float* residual, float* y, int act, int batch_w, int64_t w_bstride,
-                                  void* stream) {
+// y3_done: set by a path whose own launch wrote the requested piece image d->y3 (none does today: an 8-byte-per-lane epilogue form was
+// measured at 1.7 TB/s, slower than the separate fmi_split3_f32 pass the caller runs otherwise)
+static int fwd_impl(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias, const float* residual, float* y, int act,
+                    int batch_w, int64_t w_bstride, void* stream, bool* y3_done) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!x || !wf || !y || batch_w < 1 || act < 0 || act > 2) return FMI_ERR_BAD_ARG;
@@ -109,6 +111,37 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   ep.vec = !ep_scalar() && d->K % 4 == 0 && d->y_cstride % 4 == 0 && aligned16(y) && aligned16(bias) && aligned16(residual);
 #ifndef FMI_HOST_EMU
   const int ks = (act == 0 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->K, g.Kdim()) : 1;
+  // both operands as bf16 piece images (conv_p3.h): the activation pieces of x came from x's producer
+  static const bool p3_off = getenv("FMI_P3_OFF") != nullptr;
+  static const bool c3p3_off = getenv("FMI_C3P3_OFF") != nullptr;
+  const bool p3_any = !p3_off && batch_w == 1 && d->x_cstride == d->C && p3_generic_ok(g, d->x3, w3, d->K);
+  if (p3_any && !c3p3_off && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->dil <= 1 &&
+      conv3x3_p3_eligible(d->x3, w3, d->C, d->K, (int64_t)d->N * d->H * d->W)) {
+    C3P3Args ca{(const uint16_t*)d->x3, w3, d->N, d->H, d->W, d->C, d->K, 0, make_fastdiv(d->W), make_fastdiv(d->H * d->W)};
+    if (ks > 1) {
+      const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
+      hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
+                         d->y_cstride, total);
+      ep.bias = nullptr;
+      ep.res = nullptr;
+      ep.act = 3;
+      ep.vec = 0;
+    }
+    return launch_conv3x3_p3(ca, ep, g.Mdim(), ks, (hipStream_t)stream);
+  }
+  if (p3_any) {
+    if (ks > 1) {
+      const int64_t total = (int64_t)d->N * d->OH * d->OW * d->K;
+      hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, d->K,
+                         d->y_cstride, total);
+      ep.bias = nullptr;
+      ep.res = nullptr;
+      ep.act = 3;
+      ep.vec = 0;
+    }
+    return launch_gemm_p3(ConvK3{(const uint16_t*)d->x3, g, make_fastdiv(g.ntaps())}, ConvWX3{w3, g, (int64_t)d->kh * d->kw * d->C * d->K, d->K}, ep, g.Mdim(), d->K, g.Kdim(), ks,
+                          (hipStream_t)stream);
+  }
   static const bool c3_off = getenv("FMI_C3_OFF") != nullptr;
   const bool c3 = !c3_off && !(FMI_EXP & 32) && batch_w == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0 && d->dil <= 1 &&
                   conv3x3_eligible(x, wf, d->C, d->x_cstride, d->K, (int64_t)d->N * d->H * d->W);
@@ -141,8 +174,41 @@ extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const 
   return launch_gemm(la, lb, ep, g.Mdim(), d->K, g.Kdim(), batch_w, 1, (hipStream_t)stream);
 }
 
+static int check_y3(const fmi_conv_desc* d, int out_c, int out_cs) {
+  if (!d->y3) return FMI_OK;
+  return (out_c % 16 == 0 && out_cs == out_c && aligned16(d->y3)) ? FMI_OK : FMI_ERR_BAD_ARG;
+}
+
+extern "C" int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, const float* bias,
+                                  const float* residual, float* y, int act, int batch_w, int64_t w_bstride,
+                                  void* stream) {
+  if (!d) return FMI_ERR_BAD_ARG;
+  int rc = check_y3(d, d->K, d->y_cstride);
+  if (rc) return rc;
+  bool y3_done = false;
+  rc = fwd_impl(d, x, wf, bias, residual, y, act, batch_w, w_bstride, stream, &y3_done);
+#ifndef FMI_HOST_EMU
+  if (rc == FMI_OK && d->y3 && !y3_done) rc = fmi_split3_f32(y, d->y3, nullptr, (int64_t)d->N * d->OH * d->OW, d->K, 0, 0.f, stream);
+#endif
+  return rc;
+}
+
+static int dgrad_impl2(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias, const float* residual,
+                       const float* mask, float mslope, float* dx, int batch_w, int64_t w_bstride, void* stream, bool* y3_done);
 static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias, const float* residual,
                       const float* mask, float mslope, float* dx, int batch_w, int64_t w_bstride, void* stream) {
+  if (!d) return FMI_ERR_BAD_ARG;
+  int rc = check_y3(d, d->C, d->x_cstride);
+  if (rc) return rc;
+  bool y3_done = false;
+  rc = dgrad_impl2(d, dy, wt, bias, residual, mask, mslope, dx, batch_w, w_bstride, stream, &y3_done);
+#ifndef FMI_HOST_EMU
+  if (rc == FMI_OK && d->y3 && !y3_done) rc = fmi_split3_f32(dx, d->y3, nullptr, (int64_t)d->N * d->H * d->W, d->C, 0, 0.f, stream);
+#endif
+  return rc;
+}
+static int dgrad_impl2(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias, const float* residual,
+                       const float* mask, float mslope, float* dx, int batch_w, int64_t w_bstride, void* stream, bool* y3_done) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (!dy || !wt || !dx || batch_w < 1) return FMI_ERR_BAD_ARG;
@@ -212,6 +278,42 @@ static int dgrad_impl(const fmi_conv_desc* d, const float* dy, const float* wt, 
       ep.mask = mask;
       ep.mslope = mslope;
 #ifndef FMI_HOST_EMU
+      static const bool p3_off = getenv("FMI_P3_OFF") != nullptr;
+      const bool p3 = !p3_off && batch_w == 1 && d->y_cstride == d->K && g.Kdim() > 0 && p3_generic_ok(g, d->x3, w3, d->C);
+      const int ks_p = strided_split ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : ((s == 1 && batch_w == 1) ? conv_ksplit(g.Mdim(), d->C, g.Kdim()) : 1);
+      static const bool c3p3_off = getenv("FMI_C3P3_OFF") != nullptr;
+      if (p3 && !c3p3_off && s == 1 && d->kh == 3 && d->kw == 3 && d->pad == 1 && d->dil <= 1 &&
+          conv3x3_p3_eligible(d->x3, w3, d->K, d->C, (int64_t)d->N * d->H * d->W)) {
+        C3P3Args ca{(const uint16_t*)d->x3, w3, d->N, d->OH, d->OW, d->K, d->C, 1, make_fastdiv(d->OW), make_fastdiv(d->OH * d->OW)};
+        if (ks_p > 1) {
+          const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
+          hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
+                             d->C, d->x_cstride, total);
+          ep.bias = nullptr;
+          ep.res = nullptr;
+          ep.act = 3;
+          ep.vec = 0;
+        }
+        rc = launch_conv3x3_p3(ca, ep, g.Mdim(), ks_p, (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
+      if (p3) {
+        if (!strided_split && ks_p > 1) {
+          const int64_t total = (int64_t)d->N * d->H * d->W * d->C;
+          hipLaunchKernelGGL(conv_split_init_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, bias, residual,
+                             d->C, d->x_cstride, total);
+        }
+        if (strided_split || ks_p > 1) {
+          ep.bias = nullptr;
+          ep.res = nullptr;
+          ep.act = 3;
+          ep.vec = 0;
+        }
+        rc = launch_gemm_p3(ConvK3{(const uint16_t*)d->x3, g, make_fastdiv(g.ntaps())}, ConvWX3{w3, g, w3_stride, d->C}, ep, g.Mdim(), d->C, g.Kdim(), ks_p, (hipStream_t)stream);
+        if (rc) return rc;
+        continue;
+      }
       if (strided_split) {
         ep.bias = nullptr;
         ep.res = nullptr;

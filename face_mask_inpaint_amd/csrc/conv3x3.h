@@ -112,7 +112,13 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
                  : "memory");
   };
   auto issue = [&](int it, int st) {
+#ifdef FMI_C3_KY_OUTER
     const int ky = it / cchunks, c0 = (it - ky * cchunks) * 16;  // wave-uniform
+#else
+    // channel chunk OUTER, kernel row INNER: the three kernel rows re-read one channel chunk of neighbouring image rows while it is still in
+    // the XCD's L2 (with the kernel row outer every activation byte came three times from beyond L2)
+    const int cc_ = it / 3, ky = it - 3 * cc_, c0 = cc_ * 16;  // wave-uniform
+#endif
     const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE) * 4u + (uint32_t)wid * 1024u);  // + this wave's slot
     const uint32_t sb = sa + RA * BK * 4;
     const int64_t aoff = (int64_t)(ky - 1) * a.W * a.cs + c0;

@@ -1,0 +1,440 @@
+// Convolution forward / adjoint with BOTH operands as ready bf16 piece images (x6.h): no split arithmetic in the consuming waves.
+//
+// Activation piece image ("p3 image") of an NHWC fp32 tensor with C % 16 == 0, written by the PRODUCER of the tensor
+// (fmi_split3_f32, the convolution epilogue ConvEp::y3, the norm / activation kernels):
+//     x3[pixel][C / 16][piece 0..2][16]   bf16,  x = x0 + x1 + x2 exactly (split3_pair)
+// i.e. 96 contiguous bytes per (pixel, 16-channel group) -- exactly what one row of a 16-deep implicit-GEMM tile needs, so the
+// LDS-DMA fetches six 16-byte chunks per row from ONE 96-byte run (the fp32 tile was one 64-byte run per row).
+// Weights: the piece images fmi_weight_prepare_f32 writes, wf3 / wt3 = [piece][tap][Cred / 8][Nout][8] (ConvWX3 in gemm_core.h).
+//
+// LDS image of a stage:
+//   A: [BM rows][3 pieces][2 channel halves] 16-byte chunks (96 bytes per row); the channel half of chunk position h is h ^ ((row >> 4) & 1)
+//      (XOR on the SOURCE address of the copy and on the reader): ds_read_b128 of 32 consecutive rows at one (piece, half) is then
+//      conflict-free in the hardware's 16-lane groups (6 * row mod 16 covers the 8 even 16-byte slots per 8 rows, the swizzle moves
+//      the second 8 rows of a group onto the odd ones).
+//   B: [3 pieces][2 channel halves][BN] chunks, lane-linear in the output column.
+// One 16-deep k-step = 6 ds_read_b128 per 32 rows / columns and 6 MFMAs (v_mfma_f32_32x32x16_bf16) per 32 x 32 block.
+#pragma once
+#include "gemm_core.h"
+
+#ifndef FMI_P3_EXP
+#define FMI_P3_EXP 0  // timing experiments (wrong results): 1 A copies read the zero chunk, 2 B copies read the zero chunk, 4 no MFMAs, 8 no LDS reads in the loop, 16 no barrier
+#endif
+#ifndef FMI_HOST_EMU
+struct ConvK3 {  // A operand: gathered pixels x (tap, 16-channel group) from a p3 image
+  const uint16_t* p3;
+  ConvGeom g;  // cstride is not used: the pixel pitch of a p3 image is 3 * C elements
+  FastDiv dT;  // taps of the launch geometry.  The 16-deep k-steps walk (channel group OUTER, tap INNER): consecutive steps re-read
+               // the same channel group of neighbouring pixels while it is still in the XCD's L2 (tap-major order re-fetched the
+               // activation tile nine times from beyond L2: 3.6 GB per 8 x 128^2 256 -> 256 launch)
+  struct DCtx {
+    int64_t boff;  // element offset of (anchor pixel, piece, channel half)
+    int ry, rx;    // anchor coordinates; rows beyond M get ry far outside the image
+  };
+  struct Tile {
+    int dy, dx;
+    int64_t uoff;
+  };
+  __device__ __forceinline__ DCtx dprep(int x, int piece, int half) const {
+    DCtx d{0, -0x20000000, 0};
+    if (x >= g.Mdim()) return d;
+    const uint32_t n = fdiv((uint32_t)x, g.dG);
+    const uint32_t rem = (uint32_t)x - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    d.ry = (int)gy * g.S + g.dy0;
+    d.rx = (int)gx * g.S + g.dx0;
+    d.boff = ((int64_t)((int)n * g.IH + d.ry) * g.IW + d.rx) * (3 * g.C) + piece * 16 + half * 8;
+    return d;
+  }
+  // k-step kt (= k0 / 16) -> (channel group, tap)
+  __device__ __forceinline__ void decode(int k0, int& cg, int& tp) const {
+    const int kt = k0 >> 4;
+    cg = (int)fdiv((uint32_t)kt, dT);
+    tp = kt - cg * g.ntaps();
+  }
+  __device__ __forceinline__ Tile tile(int k0) const {
+    int cg, tp;
+    decode(k0, cg, tp);
+    const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
+    Tile t;
+    t.dy = (cg << 4) < g.C ? g.ystep * i : -0x20000000;
+    t.dx = g.xstep * j;
+    t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * (3 * g.C) + cg * 48;
+    return t;
+  }
+  // the weight tile of the same k-step: chunk row of (tap, channel group) in wf3 / wt3 = [piece][tap][Cred / 8][Nout][8]
+  __device__ __forceinline__ ConvWX3::Tile wtile(const ConvWX3& lb, int k0) const {
+    int cg, tp;
+    decode(k0, cg, tp);
+    if ((cg << 4) >= g.C) return ConvWX3::Tile{nullptr};
+    const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    return ConvWX3::Tile{lb.p3 + ((int64_t)wtap * (g.C >> 3) + cg * 2) * lb.Nout * 8};
+  }
+  __device__ __forceinline__ const uint16_t* chunk(const DCtx& d, const Tile& t) const {
+    const bool ok = (unsigned)(d.ry + t.dy) < (unsigned)g.IH && (unsigned)(d.rx + t.dx) < (unsigned)g.IW;
+    return ok ? p3 + d.boff + t.uoff : nullptr;
+  }
+};
+
+__device__ __forceinline__ void glds16_p3(const void* g, uint32_t dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(dst)
+               : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// generic implicit GEMM: rows = anchors (output pixels / adjoint phase pixels), k = (tap, channel), columns = output channels
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, ConvEp ep, int M, int N, int K, int tiles_n, int ksplit, int kchunk) {
+  constexpr int BM = T::BM, BN = T::BN, BK = 16;
+  constexpr int NIA = BM * 6 / 64, NIB = BN * 6 / 64;  // wave instructions (1 KiB each) of the A / B image of a stage
+  constexpr int NLA = (NIA + 3) / 4, NLB = (NIB + 3) / 4;
+  constexpr int ABYTES = BM * 96, STAGE = (BM + BN) * 96;
+  static_assert((BM * 6) % 64 == 0 && (BN * 6) % 64 == 0, "whole wave instructions");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int zs = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = zs * kchunk;
+  int k_end = k_begin + kchunk;
+  if (k_end > K) k_end = K;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+
+  ConvK3::DCtx da[NLA];
+  ConvWX3::DCtx db[NLB];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int p = (j * 4 + wid) * 64 + lane;  // chunk p of [BM][3][2]
+    const int row = p / 6, q = p - row * 6;
+    da[j] = la.dprep(p < BM * 6 ? m0 + row : 0x7fffffff, q >> 1, (q & 1) ^ ((row >> 4) & 1));
+  }
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int p = (j * 4 + wid) * 64 + lane;  // chunk p of [3][2][BN]
+    const int piece = p / (2 * BN), r = p - piece * (2 * BN), kg = r / BN, x = r - kg * BN;
+    db[j] = lb.dprep3(piece < 3 ? piece : 0, kg, piece < 3 ? n0 + x : 0x40000000);
+  }
+  const int na_w = (NIA - wid + 3) / 4, nb_w = (NIB - wid + 3) / 4;  // wave-uniform: instructions this wave issues per stage
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto issue = [&](int k0, int st) __attribute__((always_inline)) {
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + wid * 1024));
+    const uint32_t sb = sa + ABYTES;
+    const ConvK3::Tile ta = la.tile(k0);
+    const ConvWX3::Tile tb = la.wtile(lb, k0);
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      if (j >= na_w) break;
+      const void* g = la.chunk(da[j], ta);
+      if (!g || (FMI_P3_EXP & 1)) g = fmi_chunk_zero;
+      glds16_p3(g, sa + j * 4096);
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      if (j >= nb_w) break;
+      const void* g = lb.chunk(db[j], tb);
+      if (!g || (FMI_P3_EXP & 2)) g = fmi_chunk_zero;
+      glds16_p3(g, sb + j * 4096);
+    }
+  };
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    const unsigned char* sa = lds + st * STAGE;
+    const unsigned char* sb = sa + ABYTES;
+    bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#if FMI_P3_EXP & 8
+    for (int i = 0; i < T::TM; ++i) for (int pc = 0; pc < 3; ++pc) for (int e = 0; e < 8; ++e) pa[i][pc][e] = (__bf16)(float)(st + i + pc);
+    for (int j = 0; j < T::TN; ++j) for (int pc = 0; pc < 3; ++pc) for (int e = 0; e < 8; ++e) pb[j][pc][e] = (__bf16)(float)(st + j + pc);
+#else
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i) {
+      const int r = wm + i * 32 + l31;
+      const unsigned char* q = sa + r * 96 + ((lh ^ ((r >> 4) & 1)) << 4);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) pa[i][pc] = *reinterpret_cast<const bf16x8_t*>(q + pc * 32);
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) pb[j][pc] = *reinterpret_cast<const bf16x8_t*>(sb + pc * (2 * BN * 16) + (lh * BN + wn + j * 32 + l31) * 16);
+#endif
+#if FMI_P3_EXP & 4
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) acc[i][j][pc] += (float)pa[i][pc][0] * (float)pb[j][pc][0];
+#else
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+#endif
+  };
+
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  if (nt > 0) issue(k_begin, 0);
+  int st = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of tile t have landed
+#if !(FMI_P3_EXP & 16)
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) issue(k_begin + (t + 1) * BK, st ^ 1);
+    compute(st);
+    st ^= 1;
+  }
+  store_tile<ConvEp, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);
+}
+
+static bool p3_generic_ok(const ConvGeom& g, const void* x3, const void* w3, int Nout) {
+  return x3 && w3 && (g.C & 15) == 0 && !g.pad_mode && ((uintptr_t)x3 & 15) == 0 && ((uintptr_t)w3 & 15) == 0 && (Nout & 3) == 0 &&
+         (int64_t)g.N * g.IH * g.IW * 3 * g.C < (1ll << 40);
+}
+
+static int launch_gemm_p3(const ConvK3& la, const ConvWX3& lb, const ConvEp& ep, int M, int N, int K, int ksplit, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0 || ksplit <= 0) return FMI_ERR_BAD_ARG;
+  int kchunk = (int)ceil_div64(ceil_div64(K, ksplit), 16) * 16;
+  ksplit = (int)ceil_div64(K, kchunk);
+  if (ksplit > 65535) return FMI_ERR_UNSUPPORTED;
+#define P3_LAUNCH(TILE)                                                                                                                        \
+  do {                                                                                                                                         \
+    const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                                                  \
+    if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                                    \
+    hipLaunchKernelGGL((gemm_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn, ksplit, \
+                       kchunk);                                                                                                                \
+  } while (0)
+  auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn) * ksplit; };
+  static const int tile_dbg = getenv("FMI_P3_TILE") ? atoi(getenv("FMI_P3_TILE")) : 0;  // experiment: force a tile
+  if (tile_dbg == 1) { P3_LAUNCH(Tile128x128); return fmi_launch_status(); }
+  if (tile_dbg == 2) { P3_LAUNCH(Tile64x128); return fmi_launch_status(); }
+  if (tile_dbg == 3) { P3_LAUNCH(Tile128x64); return fmi_launch_status(); }
+  if (N <= 32) {
+    P3_LAUNCH(Tile128x32);
+  } else if (N <= 64) {
+    if (M > 64 && wgs(128, 64) >= 384) P3_LAUNCH(Tile128x64);
+    else P3_LAUNCH(Tile64x64);
+  } else {
+    if (M > 64 && wgs(128, 128) >= 800) P3_LAUNCH(Tile128x128);
+    else if (M > 32 && wgs(64, 128) >= 384) P3_LAUNCH(Tile64x128);
+    else if (M > 64 && wgs(32, 128) < 256) P3_LAUNCH(Tile64x128);
+    else P3_LAUNCH(Tile32x128);
+  }
+#undef P3_LAUNCH
+  return fmi_launch_status();
+}
+#endif
+
+#ifndef FMI_HOST_EMU
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 zero-padded convolution (forward, and the adjoint with flipped taps) with TAP REUSE along x, both operands as pieces.
+//
+// What bounds the piece-image kernels is the L2 -> LDS path (~24-28 B/clk/CU): a 128 x 128 generic tile needs 24 KB per 768 matrix
+// cycles = 32 B/clk/CU at the matrix peak (measured: the copies alone run at the equivalent of 320 TFLOP/s, copies + MFMAs at 180).
+// Here a step is one (16-channel group, kernel row): the A image holds BM + 2 consecutive pixels of the flattened [N][H][W] order at
+// image row y + ky - 1 and serves the three kx taps from fragment rows shifted by 0 / 1 / 2 (conv3x3.h); with a 256 x 128 tile on
+// 8 waves (2 per SIMD, one workgroup per CU) a step moves 60 KB for 4608 matrix cycles per SIMD = 13 B/clk/CU.
+//   LDS stage: A [RA rows][3 pieces][2 halves] chunks (half XOR (row >> 4) & 1, as above), B [3 kx][3 pieces][2 halves][BN] chunks.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WM_, int WN_, int TM_, int TN_>
+struct P3Tile {
+  static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, NW = WM * WN;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+};
+struct C3P3Args {
+  const uint16_t* x3;  // p3 image of the gathered tensor [N][H][W][C]
+  const uint16_t* w3;  // [3][9][C / 8][Nout][8]
+  int N, H, W, C, Nout, flip;
+  FastDiv dW, dHW;
+};
+
+template <class T>
+__global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
+  constexpr int BM = T::BM, BN = T::BN, NW = T::NW;
+  constexpr int NIA = ((BM + 2) * 6 + 63) / 64;  // wave instructions (1 KiB) of the A image
+  constexpr int NIB = 18 * BN / 64;              // ... of the three weight tiles
+  constexpr int NLA = (NIA + NW - 1) / NW, NLB = (NIB + NW - 1) / NW;
+  constexpr int ABYTES = NIA * 1024, STAGE = ABYTES + NIB * 1024;
+  static_assert((18 * BN) % 64 == 0, "whole wave instructions");
+  static_assert(2 * STAGE <= 160 * 1024, "two stages in LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int zs = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nit_all = 3 * (a.C >> 4);
+  const int it_begin = zs * it_chunk;
+  int it_end = it_begin + it_chunk;
+  if (it_end > nit_all) it_end = nit_all;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+  const int HW = a.H * a.W;
+
+  // A copy slots: chunk p of [RA][3][2]; row r <-> flattened pixel m0 - 1 + r
+  int64_t abase[NLA];
+  int ay[NLA];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const int p = (j * NW + wid) * 64 + lane;
+    const int r = p / 6, q = p - r * 6;
+    const int an = m0 - 1 + r;
+    ay[j] = -0x20000000;
+    abase[j] = 0;
+    if (an >= 0 && an < M && r < BM + 2) {
+      const uint32_t n = fdiv((uint32_t)an, a.dHW);
+      const uint32_t rem = (uint32_t)an - n * (uint32_t)HW;
+      ay[j] = (int)fdiv(rem, a.dW);
+      abase[j] = (int64_t)an * (3 * a.C) + (q >> 1) * 16 + (((q & 1) ^ ((r >> 4) & 1)) << 3);
+    }
+  }
+  // B copy slots: chunk p of [3 kx][3 pieces][2 halves][BN]
+  int boff[NLB], bkx[NLB];
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int p = (j * NW + wid) * 64 + lane;
+    const int per_tap = 6 * BN;
+    const int kx = p / per_tap, q = p - kx * per_tap;
+    const int piece = q / (2 * BN), r = q - piece * (2 * BN), kg = r / BN, n = r - kg * BN;
+    bkx[j] = kx | (piece << 2);
+    boff[j] = (n0 + n < a.Nout && kx < 3) ? (kg * a.Nout + n0 + n) * 8 : -1;
+  }
+  const int na_w = (NIA - wid + NW - 1) / NW, nb_w = (NIB - wid + NW - 1) / NW;
+  bool xl[T::TM], xr[T::TM];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+    const uint32_t an = (uint32_t)(m0 + wm + i * 32 + l31);
+    const uint32_t rem = an - fdiv(an, a.dHW) * (uint32_t)HW;
+    const uint32_t x = rem - fdiv(rem, a.dW) * (uint32_t)a.W;
+    xl[i] = x == 0;
+    xr[i] = x == (uint32_t)a.W - 1;
+  }
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const int64_t wpiece = (int64_t)9 * a.C * a.Nout;
+  auto issue = [&](int it, int st) __attribute__((always_inline)) {
+    const int cg = it / 3, ky = it - 3 * cg;  // wave-uniform: channel group outer, kernel row inner (L2 reuse of the activation rows)
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + wid * 1024));
+    const uint32_t sb = sa + ABYTES;
+    const int64_t aoff = (int64_t)(ky - 1) * a.W * (3 * a.C) + cg * 48;
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      if (j >= na_w) break;
+      const bool ok = (unsigned)(ay[j] + ky - 1) < (unsigned)a.H;
+      const void* g = ok ? (const void*)(a.x3 + abase[j] + aoff) : (const void*)fmi_chunk_zero;
+      glds16_p3(g, sa + (uint32_t)(j * NW * 1024));
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      if (j >= nb_w) break;
+      const int tap = ky * 3 + (bkx[j] & 3);
+      const void* g = boff[j] >= 0 ? (const void*)(a.w3 + (int64_t)(bkx[j] >> 2) * wpiece + ((int64_t)(a.flip ? 8 - tap : tap) * (a.C >> 3) + cg * 2) * a.Nout * 8 + boff[j])
+                                   : (const void*)fmi_chunk_zero;
+      glds16_p3(g, sb + (uint32_t)(j * NW * 1024));
+    }
+  };
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    const unsigned char* sa = lds + st * STAGE;
+    const unsigned char* sb = sa + ABYTES;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i) {
+        const int r = wm + i * 32 + l31 + kx;
+        const unsigned char* q = sa + r * 96 + ((lh ^ ((r >> 4) & 1)) << 4);
+        const bool zero = (kx == 0 && xl[i]) || (kx == 2 && xr[i]);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          u32x4_t v = *reinterpret_cast<const u32x4_t*>(q + pc * 32);
+          if (kx != 1) v = zero ? u32x4_t{0u, 0u, 0u, 0u} : v;
+          pa[i][pc] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          pb[j][pc] = *reinterpret_cast<const bf16x8_t*>(sb + ((kx * 3 + pc) * 2 * BN + lh * BN + wn + j * 32 + l31) * 16);
+#pragma unroll
+      for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+    }
+  };
+
+  if (it_begin < it_end) issue(it_begin, 0);
+  int st = 0;
+  for (int it = it_begin; it < it_end; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (it + 1 < it_end) issue(it + 1, st ^ 1);
+    compute(st);
+    st ^= 1;
+  }
+  store_tile<ConvEp, T>(ep, acc, M, a.Nout, m0 + wm, n0 + wn, lh, l31);
+}
+
+using C3P3_256x128 = P3Tile<4, 2, 2, 2>;  // 8 waves, 64 x 64 per wave
+using C3P3_256x64 = P3Tile<4, 2, 2, 1>;   // 8 waves, 64 x 32 per wave
+using C3P3_128x128 = P3Tile<2, 2, 2, 2>;  // 4 waves
+using C3P3_128x64 = P3Tile<4, 1, 1, 2>;   // 4 waves, every wave spans both column tiles
+
+static bool conv3x3_p3_eligible(const void* x3, const void* w3, int C, int Nout, int64_t pixels) {
+  return x3 && w3 && (C & 15) == 0 && (Nout & 3) == 0 && ((uintptr_t)x3 & 15) == 0 && ((uintptr_t)w3 & 15) == 0 && pixels < (1ll << 30);
+}
+
+static int launch_conv3x3_p3(const C3P3Args& a, const ConvEp& ep, int M, int ksplit, hipStream_t st) {
+  const int nit = 3 * (a.C >> 4);
+  if (ksplit > nit) ksplit = nit;
+  const int it_chunk = (nit + ksplit - 1) / ksplit;
+  ksplit = (nit + it_chunk - 1) / it_chunk;
+#define C3P3_LAUNCH(TILE)                                                                                                                          \
+  do {                                                                                                                                             \
+    const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(a.Nout, TILE::BN);                                                                 \
+    hipLaunchKernelGGL((conv3x3_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(TILE::NW * 64), 0, st, a, ep, M, (int)tn, ksplit, \
+                       it_chunk);                                                                                                                  \
+  } while (0)
+  auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(a.Nout, bn) * ksplit; };
+  static const int tile_dbg = getenv("FMI_C3P3_TILE") ? atoi(getenv("FMI_C3P3_TILE")) : 0;  // experiment: force a tile
+  const int N = a.Nout;
+  int pick;
+  if (tile_dbg) pick = tile_dbg;
+  else if (N > 64) pick = wgs(256, 128) >= 256 ? 1 : 3;
+  else pick = wgs(256, 64) >= 256 ? 2 : 4;
+  if (pick == 1) C3P3_LAUNCH(C3P3_256x128);
+  else if (pick == 2) C3P3_LAUNCH(C3P3_256x64);
+  else if (pick == 3) C3P3_LAUNCH(C3P3_128x128);
+  else C3P3_LAUNCH(C3P3_128x64);
+#undef C3P3_LAUNCH
+  return fmi_launch_status();
+}
+#endif

@@ -78,10 +78,10 @@ struct DenseK {  // reduction index contiguous in memory
   const float* p;
   int64_t ld, bs;
   int X, K, vec;
-  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
+  __device__ __forceinline__ void set_batch(int b) { p += (int64_t)b * bs; }
   struct Ctx {};
-  __device__ Ctx prep(int) const { return Ctx{}; }
-  __device__ float4 load4(const Ctx&, int x, int k) const {
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ float4 load4(const Ctx&, int x, int k) const {
     if (x >= X || k >= K) return zero4();
     const float* q = p + (int64_t)x * ld + k;
     if (vec && k + 3 < K) return ldg4(q);
@@ -95,7 +95,7 @@ struct DenseK {  // reduction index contiguous in memory
   // LDS-DMA path: address of the 16-byte chunk (x, k..k+3), nullptr = zeros
   // LDS-DMA path.  dprep(x, kq): per-thread constants of one copy slot (row x, k offset kq inside the tile);
   // tile(k0): wave-uniform state of a 16-deep tile; chunk(): address of the 16-byte chunk, nullptr = zeros.
-  __host__ __device__ bool dma_ok() const { return vec && (K & 3) == 0; }
+  __host__ __device__ __forceinline__ bool dma_ok() const { return vec && (K & 3) == 0; }
   struct DCtx {
     int64_t off;
     int kq;
@@ -104,11 +104,11 @@ struct DenseK {  // reduction index contiguous in memory
     const float* base;
     int krem;
   };
-  __device__ DCtx dprep(int x, int kq) const { return DCtx{(int64_t)x * ld + kq, x < X ? kq : 0x40000000}; }
-  __device__ Tile tile(int k0) const { return Tile{p + k0, K - k0}; }
-  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kq < t.krem ? t.base + d.off : nullptr; }
-  __device__ void dstart(DCtx&, int) const {}
-  __device__ void advance(DCtx&) const {}
+  __device__ __forceinline__ DCtx dprep(int x, int kq) const { return DCtx{(int64_t)x * ld + kq, x < X ? kq : 0x40000000}; }
+  __device__ __forceinline__ Tile tile(int k0) const { return Tile{p + k0, K - k0}; }
+  __device__ __forceinline__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kq < t.krem ? t.base + d.off : nullptr; }
+  __device__ __forceinline__ void dstart(DCtx&, int) const {}
+  __device__ __forceinline__ void advance(DCtx&) const {}
 };
 
 struct DenseX {  // row/column index contiguous in memory
@@ -116,10 +116,10 @@ struct DenseX {  // row/column index contiguous in memory
   const float* p;
   int64_t ld, bs;
   int X, K, vec;
-  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
+  __device__ __forceinline__ void set_batch(int b) { p += (int64_t)b * bs; }
   struct Ctx {};
-  __device__ Ctx prep(int) const { return Ctx{}; }
-  __device__ float4 load4(const Ctx&, int x, int k) const {
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ float4 load4(const Ctx&, int x, int k) const {
     if (x >= X || k >= K) return zero4();
     const float* q = p + (int64_t)k * ld + x;
     if (vec && x + 3 < X) return ldg4(q);
@@ -130,7 +130,7 @@ struct DenseX {  // row/column index contiguous in memory
     if (x + 3 < X) r.w = q[3];
     return r;
   }
-  __host__ __device__ bool dma_ok() const { return vec && (X & 3) == 0; }
+  __host__ __device__ __forceinline__ bool dma_ok() const { return vec && (X & 3) == 0; }
   struct DCtx {
     int64_t off;
     int kr;
@@ -139,11 +139,11 @@ struct DenseX {  // row/column index contiguous in memory
     const float* base;
     int krem;
   };
-  __device__ DCtx dprep(int x, int kr) const { return DCtx{(int64_t)kr * ld + x, x < X ? kr : 0x40000000}; }
-  __device__ Tile tile(int k0) const { return Tile{p + (int64_t)k0 * ld, K - k0}; }
-  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kr < t.krem ? t.base + d.off : nullptr; }
-  __device__ void dstart(DCtx&, int) const {}
-  __device__ void advance(DCtx&) const {}
+  __device__ __forceinline__ DCtx dprep(int x, int kr) const { return DCtx{(int64_t)kr * ld + x, x < X ? kr : 0x40000000}; }
+  __device__ __forceinline__ Tile tile(int k0) const { return Tile{p + (int64_t)k0 * ld, K - k0}; }
+  __device__ __forceinline__ const float* chunk(const DCtx& d, const Tile& t) const { return d.kr < t.krem ? t.base + d.off : nullptr; }
+  __device__ __forceinline__ void dstart(DCtx&, int) const {}
+  __device__ __forceinline__ void advance(DCtx&) const {}
 };
 
 // Geometry of one implicit-GEMM launch.  Rows enumerate a grid [N][GH][GW] of "anchor" positions;
@@ -159,9 +159,9 @@ struct ConvGeom {
   int pad_mode, vec;
   FastDiv dGW, dG, dC, dntx;
   int64_t img_bs;  // batch (per-sample weight mode) stride of the image
-  __host__ __device__ int ntaps() const { return nty * ntx; }
-  __host__ __device__ int Kdim() const { return nty * ntx * C; }
-  __host__ __device__ int Mdim() const { return N * GH * GW; }
+  __host__ __device__ __forceinline__ int ntaps() const { return nty * ntx; }
+  __host__ __device__ __forceinline__ int Kdim() const { return nty * ntx * C; }
+  __host__ __device__ __forceinline__ int Mdim() const { return N * GH * GW; }
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -177,8 +177,8 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
   struct Ctx {  // cached anchor of one staged row
     int ry, rx, rn;
   };
-  __device__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
-  __device__ Ctx prep(int x) const {
+  __device__ __forceinline__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
+  __device__ __forceinline__ Ctx prep(int x) const {
     Ctx c{0, 0, -1};
     if (x >= g.Mdim()) return c;
     const uint32_t n = fdiv((uint32_t)x, g.dG);
@@ -200,14 +200,14 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     ok = (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW;
     return p + ((int64_t)(c.rn * g.IH + iy) * g.IW + ix) * g.cstride;
   }
-  __device__ float elem(const Ctx& c, int k) const {
+  __device__ __forceinline__ float elem(const Ctx& c, int k) const {
     const int t = (int)fdiv((uint32_t)k, g.dC);
     if (t >= g.ntaps()) return 0.f;
     bool ok;
     const float* q = pixel(c, t, ok);
     return ok ? q[k - t * g.C] : 0.f;
   }
-  __device__ float4 load4(const Ctx& c, int, int k) const {
+  __device__ __forceinline__ float4 load4(const Ctx& c, int, int k) const {
     if (c.rn < 0) return zero4();
     if (g.vec) {  // C % 4 == 0: the four k's share a tap
       const int t = (int)fdiv((uint32_t)k, g.dC);
@@ -220,7 +220,7 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
   }
   // LDS-DMA path: only when a 16-deep tile always lies inside one tap (C % 16 == 0) and padding is zeros; the tap is then
   // wave-uniform (scalar decode per tile) and a copy's address is one 64-bit add of a per-thread and a per-tile offset.
-  __host__ __device__ bool dma_ok() const { return g.vec != 0 && (g.C & 15) == 0 && !g.pad_mode; }
+  __host__ __device__ __forceinline__ bool dma_ok() const { return g.vec != 0 && (g.C & 15) == 0 && !g.pad_mode; }
   struct DCtx {
     int64_t boff;  // element offset of (anchor pixel, channel kq); the tap adds a wave-uniform offset
     int ry, rx;    // anchor coordinates; rows beyond M get ry far outside the image
@@ -229,7 +229,7 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     int dy, dx;    // tap displacement; past the last tap: dy far outside the image (zeros)
     int64_t uoff;
   };
-  __device__ DCtx dprep(int x, int kq) const {
+  __device__ __forceinline__ DCtx dprep(int x, int kq) const {
     const Ctx c = prep(x);
     DCtx d;
     d.ry = c.rn < 0 ? -0x20000000 : c.ry;
@@ -237,7 +237,7 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     d.boff = ((int64_t)((c.rn < 0 ? 0 : c.rn) * g.IH + c.ry) * g.IW + c.rx) * g.cstride + kq;
     return d;
   }
-  __device__ Tile tile(int k0) const {
+  __device__ __forceinline__ Tile tile(int k0) const {
     const int tp = (int)fdiv((uint32_t)k0, g.dC);
     const int i = (int)fdiv((uint32_t)tp, g.dntx), j = tp - i * g.ntx;
     Tile t;
@@ -246,12 +246,12 @@ struct ConvK {  // A operand of forward / adjoint convolution: gathered pixels x
     t.uoff = ((int64_t)(g.ystep * i) * g.IW + t.dx) * g.cstride + (k0 - tp * g.C);
     return t;
   }
-  __device__ const float* chunk(const DCtx& d, const Tile& t) const {
+  __device__ __forceinline__ const float* chunk(const DCtx& d, const Tile& t) const {
     const bool ok = (unsigned)(d.ry + t.dy) < (unsigned)g.IH && (unsigned)(d.rx + t.dx) < (unsigned)g.IW;
     return ok ? p + d.boff + t.uoff : nullptr;
   }
-  __device__ void dstart(DCtx&, int) const {}
-  __device__ void advance(DCtx&) const {}
+  __device__ __forceinline__ void dstart(DCtx&, int) const {}
+  __device__ __forceinline__ void advance(DCtx&) const {}
 };
 
 struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [tap][Cred][Nout]
@@ -262,8 +262,8 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
   int64_t bs;
   int Nout, vec;
   struct Ctx {};
-  __device__ void set_batch(int b) { p += (int64_t)b * bs; }
-  __device__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ void set_batch(int b) { p += (int64_t)b * bs; }
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
   __device__ __forceinline__ const float* rowp(int k, bool& ok) const {
     const int t = (int)fdiv((uint32_t)k, g.dC);
     ok = t < g.ntaps();
@@ -271,7 +271,7 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
     const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
     return p + ((int64_t)wtap * g.C + (k - t * g.C)) * Nout;
   }
-  __device__ float4 load4(const Ctx&, int x, int k) const {
+  __device__ __forceinline__ float4 load4(const Ctx&, int x, int k) const {
     bool ok;
     const float* q = rowp(k, ok);
     if (!ok || x >= Nout) return zero4();
@@ -284,22 +284,22 @@ struct ConvWX {  // B operand of forward / adjoint convolution: packed weights [
     if (x + 3 < Nout) r.w = q[3];
     return r;
   }
-  __host__ __device__ bool dma_ok() const { return vec && (Nout & 3) == 0 && (g.C & 15) == 0; }
+  __host__ __device__ __forceinline__ bool dma_ok() const { return vec && (Nout & 3) == 0 && (g.C & 15) == 0; }
   struct DCtx {
     int off;  // kr*Nout + x, or -1 for columns beyond Nout
   };
   struct Tile {
     const float* base;  // row of (tap, first channel of the tile); nullptr past the last tap
   };
-  __device__ DCtx dprep(int x, int kr) const { return DCtx{x < Nout ? kr * Nout + x : -1}; }
-  __device__ Tile tile(int k0) const {
+  __device__ __forceinline__ DCtx dprep(int x, int kr) const { return DCtx{x < Nout ? kr * Nout + x : -1}; }
+  __device__ __forceinline__ Tile tile(int k0) const {
     bool ok;
     const float* q = rowp(k0, ok);
     return Tile{ok ? q : nullptr};
   }
-  __device__ const float* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? t.base + d.off : nullptr; }
-  __device__ void dstart(DCtx&, int) const {}
-  __device__ void advance(DCtx&) const {}
+  __device__ __forceinline__ const float* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? t.base + d.off : nullptr; }
+  __device__ __forceinline__ void dstart(DCtx&, int) const {}
+  __device__ __forceinline__ void advance(DCtx&) const {}
 };
 
 #ifndef FMI_HOST_EMU
@@ -315,25 +315,25 @@ struct ConvWX3 {
   int64_t pstride;  // elements per piece image (all taps of the kernel)
   int Nout;
   struct Ctx {};
-  __device__ void set_batch(int) {}
-  __device__ Ctx prep(int) const { return Ctx{}; }
-  __device__ float4 load4(const Ctx&, int, int) const { return zero4(); }  // register-staged path: never taken (dma_ok() is a precondition)
-  __host__ __device__ bool dma_ok() const { return (g.C & 15) == 0 && ((uintptr_t)p3 & 15) == 0; }
+  __device__ __forceinline__ void set_batch(int) {}
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ float4 load4(const Ctx&, int, int) const { return zero4(); }  // register-staged path: never taken (dma_ok() is a precondition)
+  __host__ __device__ __forceinline__ bool dma_ok() const { return (g.C & 15) == 0 && ((uintptr_t)p3 & 15) == 0; }
   struct DCtx {
     int64_t off;  // piece * pstride + (kg * Nout + x) * 8, or -1 for columns beyond Nout
   };
   struct Tile {
     const uint16_t* base;  // chunk row of (tap, first channel group of the tile); nullptr past the last tap
   };
-  __device__ DCtx dprep3(int piece, int kg, int x) const { return DCtx{x < Nout ? piece * pstride + ((int64_t)kg * Nout + x) * 8 : -1}; }
-  __device__ Tile tile(int k0) const {
+  __device__ __forceinline__ DCtx dprep3(int piece, int kg, int x) const { return DCtx{x < Nout ? piece * pstride + ((int64_t)kg * Nout + x) * 8 : -1}; }
+  __device__ __forceinline__ Tile tile(int k0) const {
     const int t = (int)fdiv((uint32_t)k0, g.dC);
     if (t >= g.ntaps()) return Tile{nullptr};
     const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
     const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
     return Tile{p3 + (((int64_t)wtap * g.C + (k0 - t * g.C)) >> 3) * Nout * 8};
   }
-  __device__ const void* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? (const void*)(t.base + d.off) : nullptr; }
+  __device__ __forceinline__ const void* chunk(const DCtx& d, const Tile& t) const { return (d.off >= 0 && t.base) ? (const void*)(t.base + d.off) : nullptr; }
 };
 #endif
 
@@ -346,8 +346,8 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
   struct Ctx {  // cached (tap, channel) of the first of the four rows a thread stages
     int t0, c0;
   };
-  __device__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
-  __device__ Ctx prep(int x) const {
+  __device__ __forceinline__ void set_batch(int b) { p += (int64_t)b * g.img_bs; }
+  __device__ __forceinline__ Ctx prep(int x) const {
     Ctx c;
     c.t0 = (int)fdiv((uint32_t)x, g.dC);
     c.c0 = x - c.t0 * g.C;
@@ -364,7 +364,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     if ((unsigned)iy >= (unsigned)g.IH || (unsigned)ix >= (unsigned)g.IW) return 0.f;
     return p[((int64_t)(n * g.IH + iy) * g.IW + ix) * g.cstride + c];
   }
-  __device__ float4 load4(const Ctx& cx, int x, int k) const {
+  __device__ __forceinline__ float4 load4(const Ctx& cx, int x, int k) const {
     const int t0 = cx.t0, c0 = cx.c0;
     if (k >= g.Mdim()) return zero4();
     if (x == ones_row) return make_float4(1.f, 0.f, 0.f, 0.f);  // ones_row is a multiple of 4 whenever it is enabled
@@ -392,7 +392,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     }
     return make_float4(v[0], v[1], v[2], v[3]);
   }
-  __host__ __device__ bool dma_ok() const { return g.vec != 0; }
+  __host__ __device__ __forceinline__ bool dma_ok() const { return g.vec != 0; }
   struct DCtx {
     Ctx c;
     int x, kr, dy, dx;
@@ -401,7 +401,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
   struct Tile {
     int k0;
   };
-  __device__ void dstart(DCtx& d, int k_begin) const {
+  __device__ __forceinline__ void dstart(DCtx& d, int k_begin) const {
     d.k = k_begin + d.kr;
     const uint32_t n = fdiv((uint32_t)d.k, g.dG);
     const uint32_t rem = (uint32_t)d.k - n * (uint32_t)(g.GH * g.GW);
@@ -410,7 +410,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     d.gy = (int)gy;
     d.gx = (int)(rem - gy * (uint32_t)g.GW);
   }
-  __device__ void advance(DCtx& d) const {
+  __device__ __forceinline__ void advance(DCtx& d) const {
     d.k += 16;
     d.gx += 16;
     while (d.gx >= g.GW) {
@@ -421,7 +421,7 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
       }
     }
   }
-  __device__ DCtx dprep(int x, int kr) const {
+  __device__ __forceinline__ DCtx dprep(int x, int kr) const {
     DCtx d;
     d.c = prep(x);
     d.x = x;
@@ -431,8 +431,8 @@ struct WgradAX {  // A operand of the weight gradient: rows = (tap, channel), re
     d.dx = g.dx0 + g.xstep * j;
     return d;
   }
-  __device__ Tile tile(int k0) const { return Tile{k0}; }
-  __device__ const float* chunk(const DCtx& d, const Tile& t) const;  // defined after the constant chunks below
+  __device__ __forceinline__ Tile tile(int k0) const { return Tile{k0}; }
+  __device__ __forceinline__ const float* chunk(const DCtx& d, const Tile& t) const;  // defined after the constant chunks below
 };
 
 // =====================================================================================
@@ -445,9 +445,9 @@ struct DenseEp {
   int64_t sc_m, sc_n, bs;
   float alpha, beta;
   int atomic;
-  __device__ void set_batch(int b) { c += (int64_t)b * bs; }
-  __device__ int64_t row_off(int row) const { return (int64_t)row * sc_m; }
-  __device__ void store(int64_t off, int col, float v) const {
+  __device__ __forceinline__ void set_batch(int b) { c += (int64_t)b * bs; }
+  __device__ __forceinline__ int64_t row_off(int row) const { return (int64_t)row * sc_m; }
+  __device__ __forceinline__ void store(int64_t off, int col, float v) const {
     float* q = c + off + (int64_t)col * sc_n;
     v *= alpha;
     if (bias) v += bias[col];
@@ -473,12 +473,12 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
   const float* mask = nullptr;
   float mslope = 0.f;
   static constexpr bool HAS_VEC4 = true;
-  __device__ void set_batch(int b) {
+  __device__ __forceinline__ void set_batch(int b) {
     y += (int64_t)b * bs;
     if (res) res += (int64_t)b * bs;
     if (mask) mask += (int64_t)b * bs;
   }
-  __device__ void store4(int64_t off, int col, float4 v) const {  // columns col .. col+3 of one row
+  __device__ __forceinline__ void store4(int64_t off, int col, float4 v) const {  // columns col .. col+3 of one row
     if (mask) {
       const float4 m4 = *reinterpret_cast<const float4*>(mask + off + col);
       v.x *= m4.x > 0.f ? 1.f : mslope, v.y *= m4.y > 0.f ? 1.f : mslope, v.z *= m4.z > 0.f ? 1.f : mslope, v.w *= m4.w > 0.f ? 1.f : mslope;
@@ -495,14 +495,14 @@ struct ConvEp {  // rows = anchors of the launch geometry, written at (gy*OS+py,
     else if (act == 2) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
     *reinterpret_cast<float4*>(y + off + col) = v;
   }
-  __device__ int64_t row_off(int row) const {
+  __device__ __forceinline__ int64_t row_off(int row) const {
     const uint32_t n = fdiv((uint32_t)row, dG);
     const uint32_t rem = (uint32_t)row - n * (uint32_t)(GH * GW);
     const uint32_t gy = fdiv(rem, dGW);
     const uint32_t gx = rem - gy * (uint32_t)GW;
     return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
   }
-  __device__ void store(int64_t off, int col, float v) const {
+  __device__ __forceinline__ void store(int64_t off, int col, float v) const {
     if (mask) v *= mask[off + col] > 0.f ? 1.f : mslope;  // linear: a split reduction masks every partial sum
     if (act == 3) {  // split reduction: y was initialised with bias + residual, the partial sums meet through fp32 atomics
       atomicAdd(y + off + col, v);
@@ -524,15 +524,15 @@ struct WgradEp {  // rows = (tap, channel) -> dwf[(wtap*C + c)*K + col], fp32 at
   int64_t bs;
   float* dbias;   // target of the extra ones-row (may be null)
   int ones_row;
-  __device__ void set_batch(int b) { dw += (int64_t)b * bs; }
-  __device__ int64_t row_off(int row) const {
+  __device__ __forceinline__ void set_batch(int b) { dw += (int64_t)b * bs; }
+  __device__ __forceinline__ int64_t row_off(int row) const {
     if (row == ones_row) return -1;
     const int t = (int)fdiv((uint32_t)row, g.dC);
     const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
     const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
     return ((int64_t)wtap * g.C + (row - t * g.C)) * Kout;
   }
-  __device__ void store(int64_t off, int col, float v) const {
+  __device__ __forceinline__ void store(int64_t off, int col, float v) const {
     if (off < 0) atomicAdd(dbias + col, v);
     else atomicAdd(dw + off + col, v);
   }
@@ -610,7 +610,7 @@ __device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T:
 static __device__ __attribute__((aligned(16))) float fmi_chunk_zero[4] = {0.f, 0.f, 0.f, 0.f};
 static __device__ __attribute__((aligned(16))) float fmi_chunk_one[4] = {1.f, 0.f, 0.f, 0.f};
 
-__device__ inline const float* WgradAX::chunk(const DCtx& d, const Tile&) const {
+__device__ __forceinline__ const float* WgradAX::chunk(const DCtx& d, const Tile&) const {
   if (d.k >= g.Mdim()) return nullptr;
   if (d.x == ones_row) return fmi_chunk_one;
   if (d.c.t0 >= g.ntaps()) return nullptr;

@@ -138,14 +138,52 @@ def eltwise(op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None, p0: floa
     return y
 
 
-def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1, w3=None) -> Tuple[ConvDesc, int, int]:
-    """w3: the bf16 piece images (PackedWeight.wf3 / .wt3) of the weight operand the call will be given, or None"""
+def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=None, dil=1, w3=None, x3=None) -> Tuple[ConvDesc, int, int]:
+    """w3: the bf16 piece images (PackedWeight.wf3 / .wt3) of the weight operand the call will be given, or None; x3: the piece image
+    (p3_of) of the ACTIVATION operand the call will be given (x for fwd, dy for dgrad), or None"""
     oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
     ow = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
     d = ConvDesc(n, h, w, c, oh, ow, k, x_cs or c, y_cs or k, kh, kw, stride, pad, pad_mode, dil)
     if w3 is not None:
         d.w3 = w3.data_ptr()
+        if x3 is not None:
+            d.x3 = x3.data_ptr()
     return d, oh, ow
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 piece images of activations (csrc/conv_p3.h): x3[pixel][C/16][3][16], x = x0 + x1 + x2 exactly.  With the pieces of BOTH operands
+# at hand a convolution runs without split arithmetic in its inner loop.  An image is cut once per tensor (by the tensor's producer where
+# that is a kernel of this library, by a fmi_split3_f32 pass otherwise) and cached on the tensor object: the forward / weight-gradient
+# pair of x and the adjoint / weight-gradient pair of dy share it.
+# ---------------------------------------------------------------------------------------------------
+P3_ENABLED = True
+P3_MIN_PIXELS = 16384  # smaller feature maps are launch / latency bound: the in-wave split costs nothing there
+
+
+def p3_wanted(pixels: int, cred: int, cout: int, taps: int) -> bool:
+    """is the piece-image path worth one split pass over the activation operand?  (reduction channels cred, output channels cout)"""
+    return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= 64 and pixels >= P3_MIN_PIXELS and taps * cout >= 576
+
+
+def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: float = 0.0) -> Optional[torch.Tensor]:
+    """piece image of the dense NHWC fp32 tensor t (cached on t).  lrelu_from: t is still EMPTY and becomes lrelu(lrelu_from, slope) in the
+    same pass that cuts its pieces."""
+    c = t.shape[-1]
+    if c % 16 or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.data_ptr() % 16:
+        if lrelu_from is not None:
+            eltwise(EW_LRELU, lrelu_from, None, slope, out=t)
+        return None
+    p = getattr(t, "_fmi_p3", None)
+    if p is not None and p[1] == t._version and lrelu_from is None:
+        return p[0]
+    x3 = torch.empty(t.numel() * 3, device=t.device, dtype=torch.bfloat16)
+    if lrelu_from is not None:
+        _L().split3_f32(_p(lrelu_from), C.c_void_p(x3.data_ptr()), _p(t), t.numel() // c, c, 1, float(slope), _st())
+    else:
+        _L().split3_f32(_p(t), C.c_void_p(x3.data_ptr()), None, t.numel() // c, c, 0, 0.0, _st())
+    t._fmi_p3 = (x3, t._version)
+    return x3
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -277,12 +315,21 @@ class _Conv2d(torch.autograd.Function):
         _chk(x, wf, bias, residual)
         lib = _L()
         x_in = x
-        if in_act is not None and in_act[0] == "apply":
-            x = eltwise(EW_LRELU, x, None, in_act[1])
         n, h, w, c = x.shape
         k = wf.shape[2]
-        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil, w3=w3[0])
+        use3 = w3[0] is not None and pad_mode == 0 and p3_wanted(n * h * w, c, k, kh * kw)
+        x3 = None
+        if in_act is not None and in_act[0] == "apply":
+            if use3:  # lrelu(x) and its piece image in one pass
+                x = torch.empty_like(x_in)
+                x3 = p3_of(x, lrelu_from=x_in, slope=in_act[1])
+            else:
+                x = eltwise(EW_LRELU, x, None, in_act[1])
+        elif use3:
+            x3 = p3_of(x)
+        d, oh, ow = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil, w3=w3[0], x3=x3)
         ctx.wt3 = w3[1]
+        ctx.x3 = x3
         y = torch.empty((n, oh, ow, k), device=x.device, dtype=torch.float32)
         with _prof(f"conv_fwd|{n}x{h}x{w} {c}->{k} k{kh}s{stride}" + (f"d{dil}" if dil > 1 else ""), 2.0 * n * oh * ow * k * c * kh * kw):
             lib.conv2d_fwd_f32(C.byref(d), _p(x), _p(wf), _p(bias), _p(residual), _p(y), act, 1, 0, _st())
@@ -325,7 +372,9 @@ class _Conv2d(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
-                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil, w3=ctx.wt3)
+                oh_, ow_ = gy.shape[1], gy.shape[2]
+                gy3 = p3_of(gy) if (ctx.wt3 is not None and p3_wanted(n * oh_ * ow_, k, c, kh * kw)) else None
+                d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil, w3=ctx.wt3, x3=gy3)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                     if ctx.in_slope is not None and gpass is not None:  # act'(x) in the epilogue, then + the other consumer's gradient
@@ -605,8 +654,10 @@ class _ConvTranspose2d(torch.autograd.Function):
         cb = wf.shape[1]
         H = (h - 1) * stride - 2 * pad + kh + out_pad
         W = (w - 1) * stride - 2 * pad + kw + out_pad
-        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=w3[1])
+        x3 = p3_of(x) if (w3[1] is not None and p3_wanted(n * h * w, cs, cb, kh * kw)) else None
+        d, oh, ow = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=w3[1], x3=x3)
         ctx.wf3 = w3[0]
+        ctx.x3 = x3
         if (oh, ow) != (h, w):
             raise FmiError("unsupported ConvTranspose2d geometry")
         y = torch.empty((n, H, W, cb), device=x.device, dtype=torch.float32)
@@ -629,8 +680,10 @@ class _ConvTranspose2d(torch.autograd.Function):
         gx = gwf = gb = gres = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            gy3 = p3_of(gy) if (ctx.wf3 is not None and p3_wanted(n * H * W, cb, cs, kh * kw)) else None
+            d0, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=ctx.wf3, x3=gy3)
             with _prof(f"convT_dgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
-                lib.conv2d_fwd_f32(C.byref(d), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
+                lib.conv2d_fwd_f32(C.byref(d0), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
             gwf = _zeros_like(wf)
             with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):

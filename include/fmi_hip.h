@@ -80,7 +80,20 @@ typedef struct {
                         piece images fmi_weight_prepare_f32 writes (entry.wf3 / entry.wt3).  fp32 products run as six bf16 MFMAs on exact
                         three-way splits of both operands; with the pieces at hand only the activations are split inside the kernel.
                         Results do not depend on whether it is given. */
+  const void* x3;    /* optional (NULL = none): the ACTIVATION operand of this call -- x for fwd, dy for dgrad -- once more as a bf16 piece
+                        image x3[pixel][C/16][piece 0..2][16] (fmi_split3_f32, or the y3 output of the call that produced the tensor).
+                        Needs a dense tensor (pixel pitch == channels), channels % 16 == 0, zero padding and w3; the convolution then
+                        runs without any split arithmetic (csrc/conv_p3.h).  Results do not depend on whether it is given. */
+  void* y3;          /* optional (NULL = none): OUT, the result of this call -- y for fwd, dx for dgrad -- once more as such a piece image
+                        (result channels % 16 == 0, dense rows), for the convolution that will consume it (today: a fmi_split3_f32 pass
+                        behind the convolution launch) */
 } fmi_conv_desc;
+
+/* bf16 piece image of a dense NHWC fp32 tensor (C % 16 == 0): x3[pixel][C/16][piece][16], x = x0 + x1 + x2 exactly, x0 = rn_bf16(x),
+ * x1 = rn_bf16(x - x0), x2 = x - x0 - x1.  op 0: pieces of x; op 1: pieces of lrelu(x, p0) (the LeakyReLU -> conv pairs of
+ * base_function.py:207-305).  y (may be NULL): also receives the fp32 value the pieces were cut from.  fmi_merge3_f32 is the inverse. */
+int fmi_split3_f32(const float* x, void* x3, float* y, int64_t pixels, int C, int op, float p0, void* stream);
+int fmi_merge3_f32(const void* x3, float* y, int64_t pixels, int C, void* stream);
 
 /* y = conv(x, wf) + bias[k] + residual ; bias/residual may be NULL.
  * act: 0 none, 1 tanh, 2 relu, applied last. residual has y's layout. */
