@@ -111,22 +111,22 @@ def build(args, device):
 
 
 def main(argv=None):
+    from .modules.evaluations.msssim import MS_SSIM
     from .modules.evaluations.ssim import ssim as ssim_func
 
+    ms_ssim_func = MS_SSIM(data_range=1, size_average=True, channel=3)  # PICNet_inference.py:130-131 in the reference
     args = get_args(argv)
     if not torch.cuda.is_available():
         raise FF.FmiError("PICNet_inference needs the MI355X (the HIP path has no CPU fallback)")
     device = torch.device("cuda:0")
     generator, mask_detector = build(args, device)
     if args.data_root:
-        from torch.utils.data import DataLoader
-
-        from .dataloader import ReferenceDataset
+        from .dataloader import DeviceLoader, ReferenceDataset
 
         j = lambda p: os.path.join(args.data_root, p)
         ds = ReferenceDataset(j(args.src_img_path), j(args.ref_img_path), j(args.mask_path), j(args.identity_file_path), apply_transform=False,
                               scale=args.img_scale, use_ssim=args.use_best_reference, device=device, return_id=True)
-        batches = DataLoader(ds, shuffle=False, drop_last=False, batch_size=args.batch_size, num_workers=0)
+        batches = DeviceLoader(ds, range(len(ds)), args.batch_size, shuffle=False, drop_last=False)  # files decoded on the host, pixels made on the GPU
     else:
         size = int(1024 * args.img_scale)
         g = torch.Generator().manual_seed(0)
@@ -138,9 +138,11 @@ def main(argv=None):
         gt = batch["raw_gt_img"].to(device)
         if args.old_model:
             gt = scale_img(gt, (218, 178))
-        results.append(evaluate(gt.contiguous(), gen_images.contiguous(), ssim_func))
+        ms = ms_ssim_func if min(gt.shape[2:]) > 160 else None  # five scales need more than (11 - 1) * 2^4 pixels per side
+        results.append(evaluate(gt.contiguous(), gen_images.contiguous().clamp(0, 1), ssim_func, ms))
     mean_ssim = sum(r[0] for r in results) / max(len(results), 1)
-    print({"ssim": mean_ssim, "batches": len(results), "image": tuple(gen_images.shape)})
+    mean_ms = sum(r[1] for r in results) / max(len(results), 1)
+    print({"ssim": mean_ssim, "ms_ssim": mean_ms, "batches": len(results), "image": tuple(gen_images.shape)})
     return mean_ssim
 
 

@@ -42,6 +42,11 @@ PD = C.POINTER(ConvDesc)
 # name -> argtypes (return type is always int status unless noted)
 SIGNATURES = {
     "fmi_gemm_f32": [vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i64, i64, i64, f32, f32, vp, vp],
+    "fmi_ssim_valid_f32": [vp, vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, i64, vp],
+    "fmi_avgpool2_pad_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "fmi_resample_u8": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp],
+    "fmi_gather_u8_i64": [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "fmi_u8_lut_chw_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "fmi_split3_f32": [vp, vp, vp, i64, i32, i32, f32, vp],
     "fmi_merge3_f32": [vp, vp, i64, i32, vp],
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],

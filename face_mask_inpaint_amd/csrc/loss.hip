@@ -421,3 +421,95 @@ extern "C" int fmi_lpips_layer_bwd_f32(const float* fx, const float* fy, const f
   hipLaunchKernelGGL(lpips_layer_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, fx, fy, w, gout, gfx, gfy, total, C, scale);
   return fmi_launch_status();
 }
+
+// ---- SSIM / MS-SSIM in the form of the trainers' metric package (pytorch_msssim, absent offline: train_reference_fill.py:207-209,
+// train_psp.py:176-178, PICNet_inference.py:130-131): Gaussian window WITHOUT padding ("valid" filtering), per plane the means of the
+// ssim map and of its contrast-structure factor cs; between the scales of MS-SSIM a 2 x 2 mean pool with zero padding of odd sizes.
+// Every workgroup writes its partial sums (fp64) and a second launch adds them in a fixed order: results are reproducible.
+__global__ void __launch_bounds__(256) ssim_valid_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ g,
+                                                         int ws, int H, int W, float C1, float C2, double* __restrict__ part) {
+  __shared__ double red[4];
+  __shared__ float sg[64];
+  if (threadIdx.x < ws) sg[threadIdx.x] = g[threadIdx.x];
+  __syncthreads();
+  const int plane = blockIdx.y, oh = H - ws + 1, ow = W - ws + 1;
+  const float* pa = a + (int64_t)plane * H * W;
+  const float* pb = b + (int64_t)plane * H * W;
+  double acc_s = 0.0, acc_c = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < oh * ow; i += gridDim.x * 256) {
+    const int y = i / ow, x = i - y * ow;
+    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int dy = 0; dy < ws; ++dy) {
+      const float* ra = pa + (int64_t)(y + dy) * W + x;
+      const float* rb = pb + (int64_t)(y + dy) * W + x;
+      float r1 = 0.f, r2 = 0.f, r11 = 0.f, r22 = 0.f, r12 = 0.f;  // the row first, then the column weight: the separable order
+      for (int dx = 0; dx < ws; ++dx) {
+        const float wgt = sg[dx], va = ra[dx], vb = rb[dx];
+        r1 += wgt * va;
+        r2 += wgt * vb;
+        r11 += wgt * va * va;
+        r22 += wgt * vb * vb;
+        r12 += wgt * va * vb;
+      }
+      const float wy = sg[dy];
+      m1 += wy * r1, m2 += wy * r2, s11 += wy * r11, s22 += wy * r22, s12 += wy * r12;
+    }
+    const float m11 = m1 * m1, m22 = m2 * m2, m12 = m1 * m2;
+    const float cs = (2.f * (s12 - m12) + C2) / ((s11 - m11) + (s22 - m22) + C2);
+    acc_c += (double)cs;
+    acc_s += (double)(((2.f * m12 + C1) / (m11 + m22 + C1)) * cs);
+  }
+  acc_s = block_sum_256_d(acc_s, red);
+  acc_c = block_sum_256_d(acc_c, red);
+  if (threadIdx.x == 0) {
+    part[((int64_t)plane * gridDim.x + blockIdx.x) * 2 + 0] = acc_s;
+    part[((int64_t)plane * gridDim.x + blockIdx.x) * 2 + 1] = acc_c;
+  }
+}
+__global__ void ssim_valid_sum_kernel(const double* __restrict__ part, int gx, int planes, double inv_count, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes * 2) return;
+  const int plane = i >> 1, which = i & 1;
+  double s = 0.0;
+  for (int j = 0; j < gx; ++j) s += part[((int64_t)plane * gx + j) * 2 + which];
+  out[i] = (float)(s * inv_count);
+}
+extern "C" int fmi_ssim_valid_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W, float C1,
+                                  float C2, float* out_plane2, double* ws_part, int64_t ws_doubles, void* stream) {
+  if (!img1 || !img2 || !window1d || !out_plane2 || !ws_part || ws <= 0 || ws > 63 || planes <= 0 || planes > 65535 || H < ws || W < ws)
+    return FMI_ERR_BAD_ARG;
+  const int64_t px = (int64_t)(H - ws + 1) * (W - ws + 1);
+  int gx = (int)((px + 255) / 256);
+  if (gx > 64) gx = 64;
+  if (ws_doubles < (int64_t)planes * gx * 2) return FMI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ssim_valid_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, img1, img2, window1d, ws, H, W, C1, C2, ws_part);
+  hipLaunchKernelGGL(ssim_valid_sum_kernel, dim3((planes * 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws_part, gx, planes, 1.0 / (double)px,
+                     out_plane2);
+  return fmi_launch_status();
+}
+// 2 x 2 mean pool, stride 2, zero padding ph / pw (0 or 1) counted in the divisor (avg_pool2d's count_include_pad default)
+__global__ void __launch_bounds__(256) avgpool2_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int OH, int OW, int ph,
+                                                           int pw, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const int64_t r = i / OW;
+    const int oy = (int)(r % OH);
+    const int64_t plane = r / OH;
+    const float* p = x + plane * H * W;
+    float s = 0.f;
+    for (int dy = 0; dy < 2; ++dy)
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = 2 * oy - ph + dy, xx = 2 * ox - pw + dx;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) s += p[(int64_t)yy * W + xx];
+      }
+    y[i] = s * 0.25f;
+  }
+}
+extern "C" int fmi_avgpool2_pad_f32(const float* x, float* y, int planes, int H, int W, int pad_h, int pad_w, void* stream) {
+  if (!x || !y || planes <= 0 || H <= 0 || W <= 0 || pad_h < 0 || pad_h > 1 || pad_w < 0 || pad_w > 1) return FMI_ERR_BAD_ARG;
+  const int OH = (H + 2 * pad_h - 2) / 2 + 1, OW = (W + 2 * pad_w - 2) / 2 + 1;
+  if (OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)planes * OH * OW;
+  hipLaunchKernelGGL(avgpool2_pad_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, OH, OW, pad_h, pad_w, total);
+  return fmi_launch_status();
+}

@@ -1,198 +1,248 @@
-"""Host-side mirror of the reference's dataloader.py (BasicDataset.preprocess / load :76-103, ReferenceDataset :122-266,
-get_reference_dataloader :19-47): CelebA(-HQ) directories of ``<id>_surgical.jpg`` sources, ``<id>.jpg`` references / ground
-truths, ``<id>.npy`` binary maps and an identity file -> the dictionary of tensors the hot path consumes:
-``src_img, gt_img, raw_gt_img, ref_img`` float32 [3, H, W] in [0, 1] (or normalised to [-1, 1] with ``apply_transform``) and
-``mask`` int64 [H, W].
+"""Data path of the inpainting trainers as a host-index + device-preprocessing pipeline.
 
-File decoding and PIL's resampling (BICUBIC for images, NEAREST for masks -- kept in PIL so that pixels equal the reference's)
-stay on the host; ``to_device_batch`` does the arithmetic on the GPU: uint8 HWC -> float32 NHWC / 255 (and (x - 0.5) / 0.5) and the
-mask binarisation ``(mask > 0).float()`` of train_reference_fill.py:340 are kernels of this library.
+What the reference's ``dataloader.py`` offers (``BasicDataset`` :49-119, ``ReferenceDataset`` :122-266, ``get_reference_dataloader``
+:19-47) is kept as an interface -- constructor arguments, the ``ids`` / ``identity_map`` / ``img2identity`` attributes, the item
+dictionary ``src_img, gt_img, raw_gt_img, ref_img`` (float32 [3, H, W] in [0, 1], or [-1, 1] with ``apply_transform``), ``mask``
+(int64 [H, W]) and optional ``id`` -- but the work is divided differently:
 
-``best_reference_map.pkl`` is this build's own cache file when it writes it; an existing one is only read if it was written by this
-class (a JSON side-car marks it) -- foreign pickles are never unpickled."""
+  host    directory listing, the identity file, jpg / npy decoding (PIL, numpy), Pillow's O(W + H) resampling tables;
+  device  BICUBIC / NEAREST resizing in Pillow's integer arithmetic, uint8 HWC -> float32 CHW / 255, Normalize, mask binarisation and
+          the SSIM scoring behind ``use_ssim`` -- kernels of libfmi_hip.so (``preprocess.DevicePreprocessor``, csrc/preproc.hip).
+
+Items and batches therefore arrive as DEVICE tensors, equal bit for bit to what the reference's CPU pipeline returns for the same files
+(tests/test_gpu_data.py against tests/golden/dataset.pt).  Batches are assembled by ``DeviceLoader``: files of a batch are decoded on a
+small thread pool and preprocessed in one launch per tensor kind -- worker processes cannot hand GPU tensors around.  There is no CPU
+preprocessing path.  The best-reference cache is a JSON file (the reference pickles it; foreign pickles are never loaded here).
+"""
 from __future__ import annotations
 
 import json
 import logging
 import math
+import os
 import random
-from os import listdir
-from os.path import splitext
-from pathlib import Path
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, Iterator, List, Optional, Sequence
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Dataset, random_split
+
+from .preprocess import DevicePreprocessor
+
+_IMAGE_KEYS = ("src_img", "gt_img", "raw_gt_img", "ref_img")
 
 
-class BasicDataset(Dataset):
-    def __init__(self, images_dir, masks_dir, scale=1.0, mask_suffix=""):
-        self.images_dir = Path(images_dir)
-        self.masks_dir = Path(masks_dir)
-        assert 0 < scale <= 1, "Scale must be between 0 and 1"
-        self.scale = scale
-        self.mask_suffix = mask_suffix
-        self.ids = [splitext(file)[0].split("_")[0] for file in listdir(images_dir) if not file.startswith(".")]
+def _stem_id(filename: str) -> str:
+    """'000123_surgical.jpg' -> '000123': the part of the file name before the first underscore / the extension"""
+    return os.path.splitext(filename)[0].split("_")[0]
+
+
+def decode(path) -> np.ndarray:
+    """file -> uint8 array ([H][W][3] for jpg / png, [H][W] for binary maps).  Only loaders that execute nothing from the file."""
+    path = str(path)
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        arr = np.load(path)  # allow_pickle stays False
+    elif ext == ".npz":
+        with np.load(path) as z:
+            arr = z[z.files[0]]
+    elif ext in (".pt", ".pth"):
+        arr = torch.load(path, weights_only=True).numpy()
+    else:
+        from PIL import Image
+
+        with Image.open(path) as im:
+            arr = np.asarray(im)
+    if arr.dtype != np.uint8:
+        raise TypeError(f"{path}: expected 8-bit data, got {arr.dtype}")
+    return np.ascontiguousarray(arr)
+
+
+def parse_identity_file(path):
+    """lines '<image file> <identity>' -> (identity -> [image ids in file order], image id -> identity)"""
+    groups: Dict[int, List[str]] = {}
+    owner: Dict[str, int] = {}
+    with open(path, "r") as fh:
+        for line in fh:
+            fields = line.split()
+            if len(fields) != 2:
+                continue
+            key, who = _stem_id(fields[0]), int(fields[1])
+            owner[key] = who
+            groups.setdefault(who, []).append(key)
+    return groups, owner
+
+
+class BasicDataset(torch.utils.data.Dataset):
+    """``<id>_surgical.jpg`` images with ``<id><mask_suffix>.npy`` binary maps -> {'image', 'mask'} on the device."""
+
+    def __init__(self, images_dir, masks_dir, scale=1.0, mask_suffix="", device=None):
+        if not 0 < scale <= 1:
+            raise AssertionError("Scale must be between 0 and 1")
+        self.images_dir, self.masks_dir = str(images_dir), str(masks_dir)
+        self.scale, self.mask_suffix = scale, mask_suffix
+        self.ids = [_stem_id(f) for f in os.listdir(self.images_dir) if not f.startswith(".")]
         if not self.ids:
             raise RuntimeError(f"No input file found in {images_dir}, make sure you put your images there")
-        logging.info(f"Creating dataset with {len(self.ids)} examples")
+        self._pre: Optional[DevicePreprocessor] = None
+        self._device = device
+        logging.info("Creating dataset with %d examples", len(self.ids))
+
+    @property
+    def pre(self) -> DevicePreprocessor:
+        if self._pre is None:
+            self._pre = DevicePreprocessor(self._device)
+        return self._pre
 
     def __len__(self):
         return len(self.ids)
 
-    @classmethod
-    def preprocess(cls, pil_img, scale, is_mask):
-        from PIL import Image
-
-        w, h = pil_img.size
-        newW, newH = int(scale * w), int(scale * h)
-        assert newW > 0 and newH > 0, "Scale is too small, resized images would have no pixel"
-        pil_img = pil_img.resize((newW, newH), resample=Image.NEAREST if is_mask else Image.BICUBIC)
-        img_ndarray = np.asarray(pil_img)
-        if img_ndarray.ndim == 2 and not is_mask:
-            img_ndarray = img_ndarray[np.newaxis, ...]
-        if not is_mask:
-            img_ndarray = img_ndarray.transpose((2, 0, 1))
-            img_ndarray = img_ndarray / 255
-            return torch.as_tensor(img_ndarray.copy()).float().contiguous()
-        return torch.as_tensor(img_ndarray.copy()).long().contiguous()
-
-    @classmethod
-    def load(cls, filename):
-        from PIL import Image
-
-        ext = splitext(filename)[1]
-        if ext in [".npz", ".npy"]:
-            return Image.fromarray(np.load(filename))  # allow_pickle stays False
-        if ext in [".pt", ".pth"]:
-            return Image.fromarray(torch.load(filename, weights_only=True).numpy())
-        return Image.open(filename)
-
     def __getitem__(self, idx):
-        name = self.ids[idx]
-        mask = self.load(self.masks_dir / Path(name + self.mask_suffix + ".npy"))
-        img = self.load(self.images_dir / Path(name + "_surgical" + ".jpg"))
-        assert img.size == mask.size, f"Image and mask {name} should be the same size, but are {img.size} and {mask.size}"
-        return {"image": self.preprocess(img, self.scale, is_mask=False), "mask": self.preprocess(mask, self.scale, is_mask=True)}
+        key = self.ids[idx]
+        img = decode(os.path.join(self.images_dir, key + "_surgical.jpg"))
+        m = decode(os.path.join(self.masks_dir, key + self.mask_suffix + ".npy"))
+        if img.shape[:2] != m.shape[:2]:
+            raise AssertionError(f"Image and mask {key} should be the same size, but are {img.shape[:2]} and {m.shape[:2]}")
+        return {"image": self.pre.images([img], self.scale)[0], "mask": self.pre.masks([m], self.scale)[0]}
 
 
 class ReferenceDataset(BasicDataset):
+    """source (masked) image, ground truth, a second image of the same identity and the binary map of the mask."""
+
     def __init__(self, source_dir, reference_dir, masks_dir, identity_file, apply_transform=True, scale=1.0, use_ssim=False, device=None,
                  return_id=False):
-        self.source_dir = Path(source_dir)
-        self.masks_dir = Path(masks_dir)
-        self.reference_dir = Path(reference_dir)
-        self.identity_map, self.img2identity = self.read_identity_file(identity_file)
-        self.filter_id = set()  # identities with only one image are ignored
-        for v in self.identity_map.values():
-            if len(v) < 2:
-                self.filter_id.update(v)
-        assert 0 < scale <= 1, "Scale must be between 0 and 1"
-        self.scale = scale
-        self.ids = []
-        for f in listdir(source_dir):
-            f_id = splitext(f)[0].split("_")[0]
-            if not f.startswith(".") and f_id not in self.filter_id:
-                self.ids.append(f_id)
+        if not 0 < scale <= 1:
+            raise AssertionError("Scale must be between 0 and 1")
+        self.source_dir, self.reference_dir, self.masks_dir = str(source_dir), str(reference_dir), str(masks_dir)
+        self.scale, self.apply_transform, self.return_id, self.use_ssim = scale, apply_transform, return_id, use_ssim
+        self.identity_map, self.img2identity = parse_identity_file(identity_file)
+        # an identity with a single image has no reference partner: its image is left out
+        self.filter_id = {members[0] for members in self.identity_map.values() if len(members) < 2}
+        self.ids = [k for k in (_stem_id(f) for f in os.listdir(self.source_dir) if not f.startswith(".")) if k not in self.filter_id]
         if not self.ids:
             raise RuntimeError(f"No input file found in {source_dir}, make sure you put your images there")
-        logging.info(f"Creating dataset with {len(self.ids)} examples")
-        self.use_ssim = use_ssim
+        self._pre, self._device = None, device
+        logging.info("Creating dataset with %d examples", len(self.ids))
         if use_ssim:
-            cache = self.source_dir.parent / Path("best_reference_map.json")
-            if cache.is_file():
-                self.best_reference_map = json.load(open(cache))
+            cache = os.path.join(os.path.dirname(os.path.normpath(self.source_dir)), "best_reference_map.json")
+            if os.path.isfile(cache):
+                with open(cache) as fh:
+                    self.best_reference_map = json.load(fh)
             else:
-                logging.info("Creating best_reference_map")
                 self.best_reference_map = self.find_best_reference(device)
-        self.apply_transform = apply_transform
-        self.return_id = return_id
+                with open(cache, "w") as fh:
+                    json.dump(self.best_reference_map, fh)
 
-    @staticmethod
-    def transform(img):
-        """transforms.Normalize([0.5] * 3, [0.5] * 3) (dataloader.py:169-170)"""
-        return (img - 0.5) / 0.5
+    # ---- which second image ----
+    def partners(self, key: str) -> List[str]:
+        return [k for k in self.identity_map[self.img2identity[key]] if k != key]
 
-    def read_identity_file(self, identity_file):
-        identity_map, img2identity = {}, {}
-        with open(identity_file, "r") as f:
-            for line in f:
-                img, identity = line.strip().split(" ")
-                img_id = splitext(img)[0].split("_")[0]
-                identity = int(identity)
-                img2identity[img_id] = identity
-                identity_map.setdefault(identity, []).append(img_id)
-        return identity_map, img2identity
-
-    def find_best_reference(self, device):
-        """for every image the same-identity image of highest SSIM (dataloader.py:188-216; the reference scores with pytorch_msssim,
-        absent offline: this build's SSIM kernel on the GPU, or its torch definition on the CPU)"""
+    def find_best_reference(self, device=None) -> Dict[str, str]:
+        """for every image the same-identity image with the highest SSIM to it, scored on the GPU by this library's SSIM kernel in one
+        batch per image (dataloader.py:188-216 scores pair by pair with pytorch_msssim, which is absent offline: parity unpinned)"""
         from .modules.evaluations.ssim import ssim as ssim_fn
 
-        dev = torch.device("cuda:0") if (device is None and torch.cuda.is_available()) else torch.device(device or "cpu")
-        if dev.type != "cuda":
-            raise RuntimeError("find_best_reference scores on the GPU (no CPU path in this library)")
+        if device is not None:
+            self._device = device
         best = {}
-        for name in self.ids:
-            gt = self.preprocess(self.load(self.reference_dir / Path(name + ".jpg")), self.scale, is_mask=False).unsqueeze(0).to(dev)
-            max_score, best_ref = -10, None
-            for other in self.identity_map[self.img2identity[name]]:
-                if other != name:
-                    rf = self.preprocess(self.load(self.reference_dir / Path(other + ".jpg")), self.scale, is_mask=False).unsqueeze(0).to(dev)
-                    score = float(ssim_fn(gt, rf))
-                    if score > max_score:
-                        max_score, best_ref = score, other
-            best[name] = best_ref
-        json.dump(best, open(self.source_dir.parent / Path("best_reference_map.json"), "w"))
+        for key in self.ids:
+            cands = self.partners(key)
+            if not cands:
+                best[key] = None
+                continue
+            imgs = self.pre.images([decode(self._ref_path(k)) for k in [key] + cands], self.scale)
+            scores = [float(ssim_fn(imgs[:1], imgs[j + 1:j + 2])) for j in range(len(cands))]
+            best[key] = cands[max(range(len(cands)), key=lambda j: (scores[j], -j))]  # first of equals, as a strict '>' scan keeps it
         return best
 
-    def sample_reference_image(self, img_name):
+    def sample_reference_image(self, img_name: str) -> str:
         if self.use_ssim:
             return self.best_reference_map[img_name]
-        images = self.identity_map[self.img2identity[img_name]]
-        assert len(images) > 1
-        reference_image = random.choice(images)
-        while reference_image == img_name:
-            reference_image = random.choice(images)
-        return reference_image
+        pool = self.identity_map[self.img2identity[img_name]]
+        if len(pool) < 2:
+            raise AssertionError(f"identity of {img_name} has no second image")
+        while True:  # draws from the WHOLE group and rejects the image itself: the random stream of the reference's sampler
+            pick = random.choice(pool)
+            if pick != img_name:
+                return pick
+
+    # ---- files ----
+    def _ref_path(self, key):
+        return os.path.join(self.reference_dir, key + ".jpg")
+
+    def _files(self, key, partner):
+        return (os.path.join(self.source_dir, key + "_surgical.jpg"), self._ref_path(key), self._ref_path(partner),
+                os.path.join(self.masks_dir, key + ".npy"))
+
+    def _load(self, key, partner):
+        src, gt, ref, m = (decode(p) for p in self._files(key, partner))
+        if src.shape[:2] != m.shape[:2]:
+            raise AssertionError(f"Image and mask {key} should be the same size, but are {src.shape[:2]} and {m.shape[:2]}")
+        return src, gt, ref, m
+
+    # ---- tensors ----
+    def assemble(self, keys: Sequence[str], partners: Sequence[str], decoded) -> Dict[str, torch.Tensor]:
+        """decoded[i] = (src, gt, ref, mask) uint8 arrays of item i -> the batch dictionary on the device: one preprocessing launch
+        sequence per tensor kind"""
+        tr = bool(self.apply_transform)
+        out = {"src_img": self.pre.images([d[0] for d in decoded], self.scale, normalise=tr),
+               "ref_img": self.pre.images([d[2] for d in decoded], self.scale, normalise=tr)}
+        out["gt_img"], out["raw_gt_img"] = self.pre.images([d[1] for d in decoded], self.scale, normalise=tr, also_plain=True)
+        out["mask"] = self.pre.masks([d[3] for d in decoded], self.scale)
+        if self.return_id:
+            out["id"] = torch.tensor([[int(k)] for k in keys], dtype=torch.int64, device=out["mask"].device)
+        return out
 
     def __getitem__(self, idx):
-        name = self.ids[idx]
-        mask = self.load(self.masks_dir / Path(name + ".npy"))
-        src_img = self.load(self.source_dir / Path(name + "_surgical" + ".jpg"))
-        gt_img = self.load(self.reference_dir / Path(name + ".jpg"))
-        ref_img = self.load(self.reference_dir / Path(self.sample_reference_image(name) + ".jpg"))
-        assert src_img.size == mask.size, f"Image and mask {name} should be the same size, but are {src_img.size} and {mask.size}"
-        src_img = self.preprocess(src_img, self.scale, is_mask=False)
-        raw_gt_img = self.preprocess(gt_img, self.scale, is_mask=False)
-        ref_img = self.preprocess(ref_img, self.scale, is_mask=False)
-        if self.apply_transform:
-            src_img, ref_img, gt_img = self.transform(src_img), self.transform(ref_img), self.transform(raw_gt_img)
-        else:
-            gt_img = raw_gt_img
-        mask = self.preprocess(mask, self.scale, is_mask=True)
-        items = {"src_img": src_img, "gt_img": gt_img, "raw_gt_img": raw_gt_img, "ref_img": ref_img, "mask": mask}
-        if self.return_id:
-            items["id"] = torch.LongTensor([int(self.ids[idx])])
-        return items
+        key = self.ids[idx]
+        partner = self.sample_reference_image(key)
+        batch = self.assemble([key], [partner], [self._load(key, partner)])
+        return {k: v[0] for k, v in batch.items()}
+
+
+class DeviceLoader:
+    """iterable over device batches of a ``ReferenceDataset`` subset (the role torch's DataLoader plays in the reference's trainers:
+    ``len()`` = number of batches, ``.dataset`` / ``.indices``, a fresh shuffle per epoch)"""
+
+    def __init__(self, dataset: ReferenceDataset, indices: Sequence[int], batch_size: int, shuffle=False, drop_last=False, num_workers=4):
+        self.dataset, self.indices = dataset, list(indices)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self.num_workers = max(1, int(num_workers))
+
+    def __len__(self):
+        n = len(self.indices)
+        return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        order = [self.indices[i] for i in torch.randperm(len(self.indices)).tolist()] if self.shuffle else list(self.indices)
+        ds = self.dataset
+        with ThreadPoolExecutor(self.num_workers) as pool:
+            for b in range(len(self)):
+                chunk = order[b * self.batch_size:(b + 1) * self.batch_size]
+                keys = [ds.ids[i] for i in chunk]
+                partners = [ds.sample_reference_image(k) for k in keys]  # on the calling thread: one random stream
+                decoded = list(pool.map(lambda kp: ds._load(*kp), zip(keys, partners)))
+                yield ds.assemble(keys, partners, decoded)
 
 
 def get_reference_dataloader(dir_src_img, dir_ref_img, dir_mask, identity_file, batch_size, apply_transform=False, val_amount=0.1, num_workers=4,
                              img_scale=1.0, use_ssim=False, device=None):
-    dataset = ReferenceDataset(dir_src_img, dir_ref_img, dir_mask, identity_file, apply_transform=apply_transform, scale=img_scale, use_ssim=use_ssim,
-                               device=device)
-    n_train = math.floor(len(dataset) * (1 - val_amount))
-    n_val = math.ceil(len(dataset) * val_amount)
-    train_set, val_set = random_split(dataset, [n_train, n_val])
-    loader_args = dict(batch_size=batch_size, num_workers=num_workers, pin_memory=True)
-    return DataLoader(train_set, shuffle=True, **loader_args), DataLoader(val_set, shuffle=False, drop_last=True, **loader_args)
+    """(train loader, validation loader) over a random split; the training loader reshuffles every epoch, the validation loader drops its
+    ragged last batch"""
+    ds = ReferenceDataset(dir_src_img, dir_ref_img, dir_mask, identity_file, apply_transform=apply_transform, scale=img_scale, use_ssim=use_ssim,
+                          device=device)
+    n_val = math.ceil(len(ds) * val_amount)
+    perm = torch.randperm(len(ds)).tolist()
+    cut = len(ds) - n_val
+    return (DeviceLoader(ds, perm[:cut], batch_size, shuffle=True, num_workers=num_workers),
+            DeviceLoader(ds, perm[cut:], batch_size, shuffle=False, drop_last=True, num_workers=num_workers))
 
 
-def to_device_batch(batch, device):
-    """the host -> device boundary of the training loops (train_reference_fill.py:337-340, train_psp.py:309-312): images to the GPU,
-    ``true_masks = (mask > 0).float()`` by the bit-exact index kernel"""
+def to_device_batch(batch, device=None):
+    """the boundary of the training loops (train_reference_fill.py:337-340, train_psp.py:309-312): every tensor on the device, plus
+    ``true_masks = (mask > 0).float()`` from the bit-exact index kernel"""
     from . import functional as FF
 
-    out = {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+    out = {k: (v if device is None or v.device == torch.device(device) else v.to(device, non_blocking=True)) for k, v in batch.items()}
     out["true_masks"] = FF.binarise_mask(out["mask"].contiguous())
     return out

@@ -89,6 +89,22 @@ typedef struct {
                         behind the convolution launch) */
 } fmi_conv_desc;
 
+/* ------------------------------------------------------------------------
+ * GPU side of the data path (dataloader.py:76-93,169-170: PIL resize, HWC -> CHW, / 255, Normalize), csrc/preproc.hip.
+ * The host decodes files and computes Pillow's O(W + H) resampling tables; the pixels are produced here in integer arithmetic and
+ * equal Pillow's bit for bit.
+ *   fmi_resample_u8: one pass of Pillow's 8-bit resampling, out = clip8((2^21 + sum in * kk) >> 22).  axis 0 (along x):
+ *     in [N][in_h][in_w][C] -> out [N][rows][out_len][C], output row y reads input row row0 + y; axis 1 (along y):
+ *     in [N][in_h][in_w][C] -> out [N][out_len][in_w][C].  bounds[out_len][2] = (first input index, count), kk[out_len][ksize] int32.
+ *   fmi_gather_u8_i64: NEAREST resize through index tables, out[n][y][x] = (int64) in[n][ytab[y]][xtab[x]]  (the mask, dataloader.py:80-91)
+ *   fmi_u8_lut_chw_f32: out[n][c][p] = lut256[in[n][p][c]]  (v / 255 and the optional Normalize as a 256-entry table)
+ * ---------------------------------------------------------------------- */
+int fmi_resample_u8(const uint8_t* in, uint8_t* out, int N, int in_h, int in_w, int C, int out_len, int axis, int row0, int rows,
+                    const int32_t* bounds, const int32_t* kk, int ksize, void* stream);
+int fmi_gather_u8_i64(const uint8_t* in, int64_t* out, int N, int in_h, int in_w, int out_h, int out_w, const int32_t* ytab,
+                      const int32_t* xtab, void* stream);
+int fmi_u8_lut_chw_f32(const uint8_t* in, const float* lut256, float* out, int N, int H, int W, int C, void* stream);
+
 /* bf16 piece image of a dense NHWC fp32 tensor (C % 16 == 0): x3[pixel][C/16][piece][16], x = x0 + x1 + x2 exactly, x0 = rn_bf16(x),
  * x1 = rn_bf16(x - x0), x2 = x - x0 - x1.  op 0: pieces of x; op 1: pieces of lrelu(x, p0) (the LeakyReLU -> conv pairs of
  * base_function.py:207-305).  y (may be NULL): also receives the fp32 value the pieces were cut from.  fmi_merge3_f32 is the inverse. */
@@ -407,6 +423,15 @@ int fmi_reduce_loss_bwd_f32(int kind, const float* a, const float* b, int64_t n,
  * out[plane / planes_per_out] += sum over the plane's pixels of the ssim map (caller zeroes out and divides). */
 int fmi_ssim_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W,
                  int planes_per_out, float* out_zeroed, void* stream);
+/* SSIM / MS-SSIM as the trainers' metric package computes them (pytorch_msssim -- third-party, absent from /root/reference and offline:
+ * train_reference_fill.py:207-209,252-257, train_psp.py:176-178, PICNet_inference.py:130-131; parity unpinned): Gaussian window
+ * WITHOUT padding; out_plane2[plane] = (mean of the ssim map, mean of its contrast-structure factor cs) over the (H-ws+1) x (W-ws+1)
+ * valid positions.  ws_part: fp64 scratch of >= planes * 64 * 2 entries (per-workgroup partial sums, added in a fixed order:
+ * reproducible).  fmi_avgpool2_pad_f32: the 2 x 2 mean pool between the scales of MS-SSIM (zero padding 0 / 1 per axis, counted in
+ * the divisor); y is [planes][(H + 2 ph - 2) / 2 + 1][(W + 2 pw - 2) / 2 + 1]. */
+int fmi_ssim_valid_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W, float C1, float C2,
+                       float* out_plane2, double* ws_part, int64_t ws_doubles, void* stream);
+int fmi_avgpool2_pad_f32(const float* x, float* y, int planes, int H, int W, int pad_h, int pad_w, void* stream);
 
 /* ------------------------------------------------------------------------
  * Contextual loss (external_function.py:231-274), x,y NHWC features [N,P,C].

@@ -12,24 +12,73 @@ DATA = os.path.join(ROOT, "tests", "golden", "dataset")
 
 
 @pytest.mark.parametrize("transform", [False, True])
-def test_reference_dataset_against_reference(golden, transform):
+def test_reference_dataset_host_side_and_oracle(golden, transform):
     """tests/golden/dataset/* are data files (jpg / npy / identity list); tests/golden/dataset.pt holds what the reference's
-    ReferenceDataset returned for them (oracle/gen_golden.py:dataset_fixture): same ids (the singleton identity filtered), same
-    tensors bit for bit (PIL decode + BICUBIC / NEAREST resize at scale 0.5, / 255, Normalize), same sampled reference image"""
-    from face_mask_inpaint_amd.dataloader import ReferenceDataset
+    ReferenceDataset returned for them (oracle/gen_golden.py:dataset_fixture).  Without a GPU this checks (a) the HOST side of the
+    rewritten data path -- same ids (the singleton identity filtered), identity groups, the reference image drawn under the fixture's
+    seeds, file decoding -- and (b) the oracle's restatement of Pillow's BICUBIC / NEAREST resizing + / 255 (+ Normalize) against the
+    reference's tensors, bit for bit.  The device kernels face the same fixture in tests/test_gpu_data.py."""
+    import numpy as np
+
+    from face_mask_inpaint_amd import dataloader as DL
+    from oracle import pil_resize_cpu as O
 
     fx = golden("dataset.pt")["transform" if transform else "plain"]
-    ds = ReferenceDataset(os.path.join(DATA, "images_masked"), os.path.join(DATA, "images"), os.path.join(DATA, "binary_map"),
-                          os.path.join(DATA, "identity.txt"), apply_transform=transform, scale=0.5, return_id=True)
-    assert sorted(ds.ids) == fx["ids"] and "108" not in ds.ids
+    ds = DL.ReferenceDataset(os.path.join(DATA, "images_masked"), os.path.join(DATA, "images"), os.path.join(DATA, "binary_map"),
+                             os.path.join(DATA, "identity.txt"), apply_transform=transform, scale=0.5, return_id=True)
+    assert sorted(ds.ids) == fx["ids"] and "108" not in ds.ids and ds.filter_id == {"108"}
+    assert ds.identity_map[2] == ["103", "104", "105"] and ds.img2identity["107"] == 3 and ds.partners("104") == ["103", "105"]
+    norm = (lambda t: (t - 0.5) / 0.5) if transform else (lambda t: t)
     for want_id, want in zip(fx["ids"], fx["items"]):
-        j = ds.ids.index(want_id)
         random.seed(1000 + int(want_id))
-        got = ds[j]
-        assert set(got) == set(want)
-        for k in want:
-            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (want_id, k)
-    assert got["mask"].dtype == torch.int64 and got["src_img"].shape == (3, 24, 20)
+        partner = ds.sample_reference_image(want_id)
+        assert partner != want_id and partner in ds.partners(want_id)
+        src, gt, ref, m = ds._load(want_id, partner)
+        assert src.dtype == np.uint8 and src.shape == (48, 40, 3) and m.shape == (48, 40)
+        f = lambda a: torch.from_numpy(O.preprocess(a, 0.5, False))
+        assert torch.equal(norm(f(src)), want["src_img"]) and torch.equal(f(gt), want["raw_gt_img"])
+        assert torch.equal(norm(f(gt)), want["gt_img"]) and torch.equal(norm(f(ref)), want["ref_img"]), (want_id, partner)
+        assert torch.equal(torch.from_numpy(O.preprocess(m, 0.5, True)), want["mask"])
+    with pytest.raises(Exception):  # pixels are made on the GPU: no CPU preprocessing path
+        if not torch.cuda.is_available():
+            ds[0]
+        else:
+            raise RuntimeError("skip")
+
+
+def test_resampling_tables_and_oracle_against_pillow():
+    """the host-side tables of face_mask_inpaint_amd.preprocess (vectorised) equal the oracle's loop restatement of Pillow's
+    precompute_coeffs / ImagingScaleAffine, and the oracle equals Pillow itself where Pillow is importable"""
+    import numpy as np
+
+    from face_mask_inpaint_amd import preprocess as P
+    from oracle import pil_resize_cpu as O
+
+    for i, o in [(48, 24), (40, 20), (1024, 256), (53, 37), (100, 33), (50, 45), (31, 31), (7, 3), (218, 54)]:
+        b, k, ks = P.bicubic_tables(i, o)
+        ob, ok, oks = O.precompute_coeffs(i, o)
+        assert ks == oks and np.array_equal(b, ob) and np.array_equal(k, ok), (i, o)
+        assert np.array_equal(P.nearest_table(i, o), O.nearest_table(i, o))
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(0)
+    for h, w, s in [(48, 40, 0.5), (64, 64, 0.25), (37, 53, 0.7), (100, 80, 0.33), (31, 29, 1.0)]:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        nw, nh = int(s * w), int(s * h)
+        assert np.array_equal(np.asarray(Image.fromarray(img).resize((nw, nh), resample=Image.BICUBIC)), O.resize_bicubic_u8(img, nw, nh))
+        m = (rng.randint(0, 2, (h, w)) * 255).astype(np.uint8)
+        assert np.array_equal(np.asarray(Image.fromarray(m).resize((nw, nh), resample=Image.NEAREST)), O.resize_nearest(m, nw, nh))
+
+
+def test_device_loader_partitions_the_dataset():
+    """get_reference_dataloader: a random split into train / validation index sets that cover the data set once; batch counts follow
+    drop_last (host logic only: iterating needs the GPU)"""
+    from face_mask_inpaint_amd import dataloader as DL
+
+    torch.manual_seed(0)
+    tr, va = DL.get_reference_dataloader(os.path.join(DATA, "images_masked"), os.path.join(DATA, "images"), os.path.join(DATA, "binary_map"),
+                                         os.path.join(DATA, "identity.txt"), batch_size=2, val_amount=0.3, img_scale=0.5)
+    assert sorted(tr.indices + va.indices) == list(range(7)) and len(va.indices) == 3 and len(tr) == 2 and len(va) == 1
+    assert tr.shuffle and not va.shuffle and va.drop_last and tr.dataset is va.dataset
 
 
 def _tiny_models():
