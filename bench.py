@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--profile-dump", default=None, help="write the per-shape launch table of the profiled step here")
     args = ap.parse_args()
 
+    from face_mask_inpaint_amd import launch
+
+    if launch.needs_spawn(args.gpus):  # started without a launcher: one child process per GPU, before this process touches the GPU
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -349,7 +353,12 @@ def main():
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         if collectives is not None:
+            import torch.distributed as dist
+            from face_mask_inpaint_amd import distributed as fdist
+
             out["collectives"] = collectives
+            out["process_group"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "exchange": fdist.default_exchange(),
+                                    "launcher": "self-spawned" if os.environ.get("FMI_SELF_SPAWNED") else "external"}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -29,6 +29,12 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
+    from face_mask_inpaint_amd import launch
+
+    if launch.needs_spawn(args.gpus):  # started without a launcher: one child process per GPU, before this process touches the GPU
+        import sys
+
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -17,6 +17,55 @@ import torch.distributed as dist
 
 _DEBUG = bool(os.environ.get("FMI_DIST_DEBUG"))
 
+# How a gradient bucket is summed over the ranks (FMI_DP_EXCHANGE, or the ``exchange`` argument of DataParallelOptimizer):
+#   "allreduce"  one all-reduce per bucket (the library picks the algorithm; a ring is bound by ONE xGMI link: 2 (n-1)/n S per link)
+#   "rs_ag"      reduce-scatter + all-gather as two collectives (S / n per link and phase when the library runs them direct)
+#   "direct"     the same exchange spelled out point-to-point: all-to-all of the n shards (every rank sends shard j straight to rank j over
+#                its own link: all 7 links of a fully connected node carry S / n at once), a local sum, all-gather of the reduced
+#                shards -- SURVEY.md 5.8 / 8e.  Also runs on gloo, so the CPU tests cover it.
+# Unmeasured on hardware: no multi-GPU node has been available to any round so far; the flag exists so that all three can be timed.
+EXCHANGES = ("allreduce", "rs_ag", "direct")
+
+
+def default_exchange() -> str:
+    e = os.environ.get("FMI_DP_EXCHANGE", "allreduce")
+    if e not in EXCHANGES:
+        raise ValueError(f"FMI_DP_EXCHANGE={e!r}: one of {EXCHANGES}")
+    return e
+
+
+class _Pending:
+    """one bucket on the wire: wait() leaves the SUM over ranks in ``flat[:n]``"""
+
+    def __init__(self, flat, n, works, shards=None, out=None):
+        self.flat, self.n, self.works, self.shards, self.out = flat, n, works, shards, out
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return self.flat[:self.n]
+
+
+def exchange_sum(flat: torch.Tensor, how: str, group=None) -> _Pending:
+    """start summing ``flat`` over the ranks, asynchronously"""
+    world = dist.get_world_size(group)
+    n = flat.numel()
+    if how == "allreduce" or world == 1:
+        return _Pending(flat, n, [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)])
+    per = (n + world - 1) // world
+    if per * world != n:  # shards of equal length
+        flat = torch.cat([flat, flat.new_zeros(per * world - n)])
+    if how == "rs_ag" and dist.get_backend(group) == "nccl":
+        shard = flat.new_empty(per)
+        w1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        w2 = dist.all_gather_into_tensor(flat, shard, group=group, async_op=True)  # stream-ordered behind the reduce-scatter
+        return _Pending(flat, n, [w1, w2], shards=shard)
+    # "direct" (and "rs_ag" on a backend without reduce-scatter): shard j of every rank goes straight to rank j
+    recv = flat.new_empty(per * world)
+    dist.all_to_all_single(recv, flat, group=group)
+    mine = recv.view(world, per).sum(0)
+    return _Pending(flat, n, [dist.all_gather_into_tensor(flat, mine, group=group, async_op=True)], shards=mine, out=recv)
+
 
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -74,10 +123,13 @@ class DataParallelOptimizer:
     rest, waits, writes the averages back into ``.grad`` and steps.  Bucket membership follows hook order, which is a
     function of the graph and therefore identical on every rank.  One backward per step (no gradient accumulation)."""
 
-    def __init__(self, optimizer: torch.optim.Optimizer, bucket_bytes: int = 16 << 20, group=None):
+    def __init__(self, optimizer: torch.optim.Optimizer, bucket_bytes: int = 16 << 20, group=None, exchange=None):
         self.optimizer = optimizer
         self.bucket_bytes = bucket_bytes
         self.group = group
+        self.exchange = exchange or default_exchange()
+        if self.exchange not in EXCHANGES:
+            raise ValueError(f"exchange={self.exchange!r}: one of {EXCHANGES}")
         self._open: List[torch.nn.Parameter] = []
         self._open_bytes = 0
         self._inflight = []  # (work, flat, params)
@@ -105,7 +157,7 @@ class DataParallelOptimizer:
             import sys
             print(f"[fmi.dist r{dist.get_rank()}] bucket #{self.collectives} of {type(self.optimizer).__name__}@{id(self) & 0xffff:x}: "
                   f"{len(params)} tensors, {flat.numel() * 4} bytes", file=sys.stderr, flush=True)
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = exchange_sum(flat, self.exchange, self.group)
         self._inflight.append((work, flat, params, [p.grad.numel() for p in params]))
         self.collectives += 1
 
@@ -113,7 +165,7 @@ class DataParallelOptimizer:
         self.launch()
         world = dist.get_world_size(self.group)
         for work, flat, params, sizes in self._inflight:
-            work.wait()
+            flat = work.wait()
             flat.div_(world)
             dst, views, off = [], [], 0
             for p, n in zip(params, sizes):

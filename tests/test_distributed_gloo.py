@@ -31,7 +31,7 @@ def _data(rank):
     return torch.randn(5, 6, generator=g), torch.randn(5, 3, generator=g)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from face_mask_inpaint_amd import distributed as fd
@@ -42,7 +42,7 @@ def _worker(rank, world, port, out):
             for p in m.parameters():
                 p.add_(1.0)
     fd.broadcast_parameters([m])
-    opt = fd.DataParallelOptimizer(torch.optim.Adam(m.parameters(), lr=1e-2), bucket_bytes=256)  # forces several buckets
+    opt = fd.DataParallelOptimizer(torch.optim.Adam(m.parameters(), lr=1e-2), bucket_bytes=256, exchange=exchange)  # forces several buckets
     x, y = _data(rank)
     for _ in range(3):
         opt.zero_grad()
@@ -53,9 +53,12 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_exchange(tmp_path):
+@pytest.mark.parametrize("exchange", ["allreduce", "direct", "rs_ag"])
+def test_two_rank_gradient_exchange(tmp_path, exchange):
+    """exchange: one all-reduce per bucket, or the point-to-point reduce-scatter + all-gather (all-to-all of the shards, local sum,
+    all-gather; "rs_ag" takes that form on gloo, which has no reduce-scatter) with bucket lengths that are not multiples of the world size"""
     port, out = _free_port(), str(tmp_path / "sd")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, exchange), nprocs=2, join=True)
     a, b = torch.load(out + ".0"), torch.load(out + ".1")
     for k in a:
         assert torch.equal(a[k], b[k]), k
