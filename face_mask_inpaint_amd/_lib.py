@@ -135,6 +135,7 @@ SIGNATURES = {
     "fmi_cx_bwd_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp],
     "fmi_adam_step_f32": [vp, i32, i64, f32, f32, f32, f32, f32, i32, vp],
     "fmi_adam_step_dev_f32": [vp, i32, f32, f32, f32, f32, f32, vp, vp],
+    "fmi_adam_step_dev_guarded_f32": [vp, i32, f32, f32, f32, f32, f32, vp, vp, vp],
     "fmi_ranger_step_f32": [vp, i32, f32, f32, f32, f32, f32, f32, i32, f32, i32, vp],
     "fmi_upfirdn2d_f32": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fmi_upfirdn2d_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

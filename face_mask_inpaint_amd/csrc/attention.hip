@@ -19,6 +19,20 @@
 #include "x6.h"
 #include <cstdlib>
 
+// > 64 KB of dynamic LDS must be opted into per kernel AND per device (hipFuncSetAttribute acts on the current device's code object):
+// one atomic flag per (kernel instantiation, device ordinal), safe from the forward and the autograd thread alike
+struct fmi_attr_flags {
+  unsigned char done[64];
+};
+static inline bool fmi_attr_needed(fmi_attr_flags& f, int& dev) {
+  dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  return !__atomic_load_n(&f.done[dev], __ATOMIC_ACQUIRE);
+}
+static inline void fmi_attr_mark(fmi_attr_flags& f, int dev) {
+  if (dev >= 0 && dev < 64) __atomic_store_n(&f.done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+}
+
 #define ATT_THR 20.0f
 
 
@@ -375,11 +389,11 @@ extern "C" int fmi_attention_fwd_f32(const float* q, const float* v1, const floa
 #define ATT_LAUNCH1(DD, NN, WW)                                                                                                \
   do {                                                                                                                        \
     constexpr int lds_bytes = 2 * 3 * 32 * ((2 * DD + 16) + (2 * NN * 32 + 64));                                               \
-    static bool attr_set = false; /* > 64 KB of dynamic LDS must be opted into once per kernel */                              \
-    if (!attr_set) {                                                                                                          \
+    static fmi_attr_flags attr_set{}; int attr_set_dev;\
+    if (fmi_attr_needed(attr_set, attr_set_dev)) {                                                                                                          \
       if (hipFuncSetAttribute((const void*)attn_fwd_x6_kernel<DD, NN, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) \
         return FMI_ERR_LAUNCH;                                                                                                \
-      attr_set = true;                                                                                                        \
+      fmi_attr_mark(attr_set, attr_set_dev);                                                                                                        \
     }                                                                                                                         \
     hipLaunchKernelGGL((attn_fwd_x6_kernel<DD, NN, WW>), grid, block, lds_bytes, st, q, v1, v2, o1, o2, lse, T, C1, C2);       \
   } while (0)
@@ -1187,12 +1201,12 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
     static const bool one_pass = getenv("FMI_ATT_BWD_2PASS") == nullptr;
 #define ATTB2_X6(DD, NN, LO, CNT, FULLP)                                                                                 \
   do {                                                                                                                   \
-    static bool attr_setx = false;                                                                                       \
-    if (!attr_setx) {                                                                                                    \
+    static fmi_attr_flags attr_setx{}; int attr_setx_dev;\
+    if (fmi_attr_needed(attr_setx, attr_setx_dev)) {                                                                                                    \
       if (hipFuncSetAttribute((const void*)attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)lds2x(DD, NN * 32)) != hipSuccess)                                                    \
         return FMI_ERR_LAUNCH;                                                                                           \
-      attr_setx = true;                                                                                                  \
+      fmi_attr_mark(attr_setx, attr_setx_dev);                                                                                                  \
     }                                                                                                                    \
     hipLaunchKernelGGL((attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>), grid2, block, lds2x(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
                        (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
@@ -1208,12 +1222,12 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
       }                                                                                                                  \
       return fmi_launch_status();                                                                                        \
     }                                                                                                                    \
-    static bool attr_set2 = false;                                                                                       \
-    if (!attr_set2) {                                                                                                    \
+    static fmi_attr_flags attr_set2{}; int attr_set2_dev;\
+    if (fmi_attr_needed(attr_set2, attr_set2_dev)) {                                                                                                    \
       if (hipFuncSetAttribute((const void*)attn_bwd2_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
                               (int)lds2(DD, NN * 32)) != hipSuccess)                                                     \
         return FMI_ERR_LAUNCH;                                                                                           \
-      attr_set2 = true;                                                                                                  \
+      fmi_attr_mark(attr_set2, attr_set2_dev);                                                                                                  \
     }                                                                                                                    \
     hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse,         \
                        (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
@@ -1230,12 +1244,12 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
   auto lds_bytes = [](int d, int ct) { return sizeof(float) * (size_t)(2 * 32 * (ct + 1) + 2 * 32 * (d + 1) + 64 + 4 * 2 * 1024 + 2 * 32 * 33); };
 #define ATTB_LAUNCH(DD, NN)                                                                                              \
   do {                                                                                                                   \
-    static bool attr_set = false; /* > 64 KB of dynamic LDS must be opted into once per kernel */                         \
-    if (!attr_set) {                                                                                                     \
+    static fmi_attr_flags attr_set{}; int attr_set_dev;\
+    if (fmi_attr_needed(attr_set, attr_set_dev)) {                                                                                                     \
       if (hipFuncSetAttribute((const void*)attn_bwd_kernel<DD, NN>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                               (int)lds_bytes(DD, NN * 32)) != hipSuccess)                                                \
         return FMI_ERR_LAUNCH;                                                                                           \
-      attr_set = true;                                                                                                   \
+      fmi_attr_mark(attr_set, attr_set_dev);                                                                                                   \
     }                                                                                                                    \
     hipLaunchKernelGGL((attn_bwd_kernel<DD, NN>), grid, block, lds_bytes(DD, NN * 32), st, q, v1, v2, go1, go2, lse,      \
                        (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \

@@ -317,7 +317,19 @@ struct ConvWX3 {
   struct Ctx {};
   __device__ __forceinline__ void set_batch(int) {}
   __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
-  __device__ __forceinline__ float4 load4(const Ctx&, int, int) const { return zero4(); }  // register-staged path: never taken (dma_ok() is a precondition)
+  // register-staged path (FMI_DMA_OFF / FMI_DMA_OFF_RANGE / FMI_EXP & 32 debugging, or a loader pair without LDS-DMA): the fp32 weight is
+  // the exact sum of its three pieces, added from the smallest up
+  __device__ __forceinline__ float elem(int x, int k) const {
+    const int t = (int)fdiv((uint32_t)k, g.dC);
+    if (t >= g.ntaps() || x >= Nout) return 0.f;
+    const int i = (int)fdiv((uint32_t)t, g.dntx), j = t - i * g.ntx;
+    const int wtap = (g.kh0 + g.khstep * i) * g.kw + (g.kw0 + g.kwstep * j);
+    const int c = k - t * g.C;
+    const uint16_t* q = p3 + (((int64_t)wtap * g.C + c) >> 3) * Nout * 8 + (int64_t)x * 8 + (c & 7);
+    const float x0 = __uint_as_float((uint32_t)q[0] << 16), x1 = __uint_as_float((uint32_t)q[pstride] << 16), x2 = __uint_as_float((uint32_t)q[2 * pstride] << 16);
+    return (x2 + x1) + x0;
+  }
+  __device__ __forceinline__ float4 load4(const Ctx&, int x, int k) const { return make_float4(elem(x, k), elem(x + 1, k), elem(x + 2, k), elem(x + 3, k)); }
   __host__ __device__ __forceinline__ bool dma_ok() const { return (g.C & 15) == 0 && ((uintptr_t)p3 & 15) == 0; }
   struct DCtx {
     int64_t off;  // piece * pstride + (kg * Nout + x) * 8, or -1 for columns beyond Nout

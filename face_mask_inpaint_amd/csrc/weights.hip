@@ -173,6 +173,10 @@ extern "C" int fmi_weight_prepare_f32(const fmi_weight_entry* entries, int count
     if (e.u && (!e.v || !e.sigma)) return FMI_ERR_BAD_ARG;
     if (e.u && e.rows > SN_MAX_ROWS) return FMI_ERR_UNSUPPORTED;
     if (e.iters < 0 || e.iters > 64) return FMI_ERR_BAD_ARG;
+    // piece images are written by the tiled path only (taps <= TR_MAX, 8-channel groups inside a tile): anything else would leave
+    // the caller's buffer uninitialised while fmi_conv2d_* trusted it
+    if (e.wf3 && (e.taps > TR_MAX || (tr_cc(e.taps) & 7) || (e.C & 7))) return FMI_ERR_UNSUPPORTED;
+    if (e.wt3 && (e.taps > TR_MAX || (e.rows & 7))) return FMI_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += ENTRY_CHUNK) {
@@ -338,12 +342,18 @@ extern "C" int fmi_adam_step_f32(const fmi_adam_entry* entries, int count, int64
 
 // The same update with the step count in DEVICE memory (incremented by the launch sequence itself): nothing about the step is baked
 // into the launch arguments, so a training step captured in a HIP graph replays with the right bias corrections.
-__global__ void adam_step_inc_kernel(int* step) { step[0] += 1; }
+// guard (may be null): a device scalar, normally the loss of the step; a non-finite value turns the whole step into a no-op (counter
+// included) -- the "skip the step if the loss is not finite" of train_psp.py:328-331 as a device-side predicate, so that a HIP-graph
+// replay needs no host read
+__device__ __forceinline__ bool adam_guard_ok(const float* guard) { return !guard || isfinite(guard[0]); }
+__global__ void adam_step_inc_kernel(int* step, const float* guard) {
+  if (adam_guard_ok(guard)) step[0] += 1;
+}
 __global__ void __launch_bounds__(256) adam_dev_kernel(const AdamArgs args, float lr, float beta1, float beta2, float eps, float wd,
-                                                       const int* __restrict__ step) {
+                                                       const int* __restrict__ step, const float* __restrict__ guard) {
   const fmi_adam_entry e = args.e[blockIdx.y];
   const int64_t base = (int64_t)blockIdx.x * ADAM_CHUNK;
-  if (base >= e.n) return;
+  if (base >= e.n || !adam_guard_ok(guard)) return;
   const int st = step[0];
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)st));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)st));
@@ -360,11 +370,17 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(const AdamArgs args, floa
     e.p[i] = p - step_size * (m / denom);
   }
 }
+extern "C" int fmi_adam_step_dev_guarded_f32(const fmi_adam_entry* entries, int count, float lr, float beta1, float beta2, float eps,
+                                             float weight_decay, int* step_dev, const float* guard, void* stream);
 extern "C" int fmi_adam_step_dev_f32(const fmi_adam_entry* entries, int count, float lr, float beta1, float beta2, float eps,
                                      float weight_decay, int* step_dev, void* stream) {
+  return fmi_adam_step_dev_guarded_f32(entries, count, lr, beta1, beta2, eps, weight_decay, step_dev, nullptr, stream);
+}
+extern "C" int fmi_adam_step_dev_guarded_f32(const fmi_adam_entry* entries, int count, float lr, float beta1, float beta2, float eps,
+                                             float weight_decay, int* step_dev, const float* guard, void* stream) {
   if (!entries || count <= 0 || !step_dev) return FMI_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev);
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, st, step_dev, guard);
   for (int base = 0; base < count; base += ENTRY_CHUNK * 2) {
     AdamArgs a;
     const int n = count - base < ENTRY_CHUNK * 2 ? count - base : ENTRY_CHUNK * 2;
@@ -376,7 +392,7 @@ extern "C" int fmi_adam_step_dev_f32(const fmi_adam_entry* entries, int count, f
     }
     const int64_t gx = ceil_div64(mx, ADAM_CHUNK);
     if (gx > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, n), dim3(256), 0, st, a, lr, beta1, beta2, eps, weight_decay, (const int*)step_dev);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)gx, n), dim3(256), 0, st, a, lr, beta1, beta2, eps, weight_decay, (const int*)step_dev, guard);
   }
   return fmi_launch_status();
 }

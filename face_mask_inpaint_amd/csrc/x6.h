@@ -18,7 +18,9 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // two fp32 values -> three words, word i = {piece i of a (low half), piece i of b (high half)}.  Round-to-nearest pieces (v_cvt_pk_bf16_f32):
 // x0 = rn(x), x1 = rn(x - x0), x2 = x - x0 - x1 -- both differences are exact in fp32 and x2 has at most 8 significant bits, so
 // x = x0 + x1 + x2 exactly, with |x1| <= 2^-9 |x| and |x2| <= 2^-18 |x|.  (Truncated pieces cost the same 11 instructions per pair but
-// leave dropped cross terms four times larger and all of one sign.)  An infinite input yields NaN (inf - inf), not inf.
+// leave dropped cross terms four times larger and all of one sign.)  An infinite input yields NaN (inf - inf), not inf.  A piece that is a
+// bf16 SUBNORMAL (|piece| < 2^-126: the third piece of |x| < 2^-100, the second of |x| < 2^-117) is flushed to zero by the matrix pipe: such
+// operands degrade towards bf16 accuracy (tests/test_gpu_kernels.py::test_bf16x6_edge_values_on_the_matrix_pipe pins the behaviour).
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
   const bf16x2_t h = {(__bf16)a, (__bf16)b};

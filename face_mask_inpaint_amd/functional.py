@@ -347,7 +347,7 @@ class _Conv2d(torch.autograd.Function):
         lib = _L()
         x, wf, y = ctx.saved_tensors
         if gy is None:
-            return (gpass,) + (None,) * 16
+            return (gpass,) + (None,) * 15
         kh, kw, stride, pad, pad_mode, act = ctx.cfg
         gy = gy.contiguous()
         if act and not ctx.skip_act_bwd:
@@ -1985,9 +1985,10 @@ class _BiasAdd(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------
 # multi-tensor Adam
 # ---------------------------------------------------------------------------------------------------
-def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay=0.0):
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps, weight_decay=0.0, guard=None):
     """step: python int (bias corrections computed on the host), or a 1-element int32 DEVICE tensor holding the number of steps taken
-    so far (incremented by the launch; graph-capturable)"""
+    so far (incremented by the launch; graph-capturable).  guard (device-counter form only): a device scalar -- the step becomes a
+    no-op when it is not finite (train_psp.py:328-331)"""
     n = len(params)
     if n == 0:
         return
@@ -1999,8 +2000,15 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step, lr, beta1, beta2, eps,
             _chk(p, g, m, v)
             e = entries[i]
             e.p, e.g, e.m, e.v, e.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-        _L().adam_step_dev_f32(entries, n, lr, beta1, beta2, eps, weight_decay, C.c_void_p(step.data_ptr()), _st())
+        if guard is not None:
+            if guard.dtype != torch.float32 or not guard.is_cuda or guard.numel() != 1:
+                raise FmiError("the guard must be a 1-element float32 device tensor")
+            _L().adam_step_dev_guarded_f32(entries, n, lr, beta1, beta2, eps, weight_decay, C.c_void_p(step.data_ptr()), _p(guard), _st())
+        else:
+            _L().adam_step_dev_f32(entries, n, lr, beta1, beta2, eps, weight_decay, C.c_void_p(step.data_ptr()), _st())
         return
+    if guard is not None:
+        raise FmiError("a guarded step needs the device step counter (FusedAdam(capturable=True))")
     entries = (_lib.AdamEntry * n)()
     mx = 0
     for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):

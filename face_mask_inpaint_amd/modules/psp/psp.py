@@ -45,7 +45,7 @@ class pSp(nn.Module):
     def load_weights(self):
         self.latent_avg = None
         if getattr(self.opts, "pt_ckpt_path", None) is not None:
-            ckpt = torch.load(self.opts.pt_ckpt_path, map_location="cpu")
+            ckpt = torch.load(self.opts.pt_ckpt_path, map_location="cpu", weights_only=True)
             self.encoder.load_state_dict(get_keys(ckpt, "encoder"), strict=False)
             self.decoder.load_state_dict(get_keys(ckpt, "decoder"), strict=True)
             self.__load_latent_avg(ckpt)
@@ -53,8 +53,8 @@ class pSp(nn.Module):
         if not (os.path.exists(model_paths["ir_se50"]) and os.path.exists(getattr(self.opts, "stylegan_weights", None) or model_paths["stylegan_ffhq"])):
             print("pSp: pretrained weight files not found -> keeping the random initialisation")
             return
-        self.encoder.load_state_dict(torch.load(model_paths["ir_se50"]), strict=False)
-        ckpt = torch.load(self.opts.stylegan_weights if getattr(self.opts, "stylegan_weights", None) else model_paths["stylegan_ffhq"])
+        self.encoder.load_state_dict(torch.load(model_paths["ir_se50"], map_location="cpu", weights_only=True), strict=False)
+        ckpt = torch.load(self.opts.stylegan_weights if getattr(self.opts, "stylegan_weights", None) else model_paths["stylegan_ffhq"], map_location="cpu", weights_only=True)
         self.decoder.load_state_dict(ckpt["g_ema"], strict=False)
         self.__load_latent_avg(ckpt, repeat=1 if self.opts.learn_in_w else self.opts.n_styles)
 

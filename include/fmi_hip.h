@@ -462,6 +462,11 @@ int fmi_adam_step_f32(const fmi_adam_entry* entries /* HOST array */, int count,
  * the device from it -- a training step captured in a HIP graph (torch.cuda.graph) replays with the right corrections */
 int fmi_adam_step_dev_f32(const fmi_adam_entry* entries /* HOST array */, int count, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int* step_dev, void* stream);
+/* the same with a device-side guard: when guard[0] (a device scalar, normally the loss of this step) is not finite the call changes
+ * nothing -- parameters, moments and the step count keep their values: train_psp.py:328-331 ("skip the step if the loss is not finite")
+ * without a host read, so it survives HIP-graph capture.  guard == NULL: fmi_adam_step_dev_f32. */
+int fmi_adam_step_dev_guarded_f32(const fmi_adam_entry* entries /* HOST array */, int count, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, int* step_dev, const float* guard, void* stream);
 /* multi-tensor Ranger step = RAdam + Lookahead + gradient centralisation (modules/psp/ranger.py:92-184, the --optimizer ranger of
  * train_psp.py:290-293).  row_mean (scratch, rows floats) non-NULL = centralise: g -= mean of its row (tensors with more than one
  * dimension, cols = numel / shape[0]); step_size / rectified from the host (the RAdam variance rectification depends on the step

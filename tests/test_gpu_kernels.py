@@ -782,3 +782,132 @@ def test_fused_attention_backward_key_block_structure(dev, FF, n, t, d, cs):
     assert float((gq - gq64).abs().max()) <= 2e-5 * scale + 1e-6, (float((gq - gq64).abs().max()), scale)  # measured ~3e-6 of the largest entry
     for vd, v in zip(vds, v64):
         torch.testing.assert_close(vd.grad.double(), v.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_adam_guard_skips_a_non_finite_step(dev, FF):
+    """FusedAdam(capturable=True).step(guard=loss): a NaN / inf device scalar turns the step into a no-op -- parameters, both moments and
+    the device step count unchanged (train_psp.py:328-331 as a device-side predicate); a finite guard equals the unguarded step"""
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    torch.manual_seed(0)
+    p0 = torch.randn(1000, device=dev)
+    g = torch.randn(1000, device=dev)
+    pa, pb = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa, ob = FusedAdam([pa], lr=1e-2, capturable=True), FusedAdam([pb], lr=1e-2, capturable=True)
+    for guard in (torch.tensor([1.5], device=dev), torch.tensor([float("nan")], device=dev), torch.tensor([float("inf")], device=dev),
+                  torch.tensor([0.25], device=dev)):
+        pa.grad, pb.grad = g.clone(), g.clone()
+        before = (pa.detach().clone(), int(oa.param_groups[0].get("step_dev", torch.zeros(1)).item()))
+        oa.step(guard=guard)
+        if torch.isfinite(guard).item():
+            ob.step()
+            assert torch.equal(pa.detach(), pb.detach())
+        else:
+            assert torch.equal(pa.detach(), before[0]) and int(oa.param_groups[0]["step_dev"].item()) == before[1]
+    assert int(oa.param_groups[0]["step_dev"].item()) == 2 == int(ob.param_groups[0]["step_dev"].item())
+    assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+
+
+def test_fused_adam_state_dict_crosses_modes(dev, FF):
+    """state written by the capturable path (device counter) loads into the host-counter path and back, through a CPU round trip, and the
+    continued trajectories equal an uninterrupted torch.optim.Adam run (<= 1e-6: same update arithmetic)"""
+    from face_mask_inpaint_amd.optim import FusedAdam
+
+    torch.manual_seed(1)
+    w0 = torch.randn(257, device=dev)
+    grads = [torch.randn(257, device=dev) for _ in range(6)]
+    ref = torch.nn.Parameter(w0.clone())
+    oref = torch.optim.Adam([ref], lr=1e-2)
+    for g in grads:
+        ref.grad = g.clone()
+        oref.step()
+    p = torch.nn.Parameter(w0.clone())
+    o = FusedAdam([p], lr=1e-2, capturable=True)
+    for g in grads[:2]:
+        p.grad = g.clone()
+        o.step()
+    import io
+
+    buf = io.BytesIO()
+    torch.save(o.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu", weights_only=True)  # a checkpoint read back on the CPU: the counter arrives as a CPU tensor
+    o2 = FusedAdam([p], lr=1e-2, capturable=False)
+    o2.load_state_dict(sd)
+    for g in grads[2:4]:
+        p.grad = g.clone()
+        o2.step()
+    assert o2.state[p]["step"] == 4
+    o3 = FusedAdam([p], lr=1e-2, capturable=True)
+    o3.load_state_dict(o2.state_dict())
+    for g in grads[4:]:
+        p.grad = g.clone()
+        o3.step()
+    assert int(o3.param_groups[0]["step_dev"].item()) == 6 and o3.param_groups[0]["step_dev"].is_cuda
+    torch.testing.assert_close(p.detach(), ref.detach(), rtol=1e-6, atol=1e-6)
+
+
+def test_weight_pieces_on_the_register_staged_kernel():
+    """FMI_DMA_OFF=2 (debug switch of tools/bench_tools/bisect.py, trace.py) sends convolutions to the register-staged kernel; with piece
+    images of the weights given (fmi_conv_desc.w3) that kernel now rebuilds the fp32 weight from the pieces -- round 2 read zeros there.
+    The switch is read once per process, so this runs in a child process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import ctypes as C, torch
+from face_mask_inpaint_amd import functional as FF, _lib
+dev = torch.device("cuda:0"); lib = _lib.lib(); st = FF._st()
+g = torch.Generator().manual_seed(3)
+w = (torch.randn(32, 32, 3, 3, generator=g) * 0.1).to(dev)
+(pw,) = FF.prepare_weights([(w, None, None)])
+x = torch.randn(2, 20, 20, 32, generator=g).to(dev)
+outs = []
+for w3 in (None, pw.w3[0]):
+    d, oh, ow = FF.conv_desc(2, 20, 20, 32, 32, 3, 3, 2, 1, w3=w3)   # stride 2: the generic loader pair
+    y = torch.full((2, oh, ow, 32), float("nan"), device=dev)
+    lib.conv2d_fwd_f32(C.byref(d), FF._p(x), FF._p(pw.wf.detach()), None, None, FF._p(y), 0, 1, 0, st)
+    outs.append(y)
+assert float(outs[0].abs().max()) > 0.1
+assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * float(outs[0].abs().max()), float((outs[0] - outs[1]).abs().max())
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FMI_DMA_OFF="2", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bf16x6_edge_values_on_the_matrix_pipe(dev, FF):
+    """what csrc/x6.h documents, pinned on the MFMA path: (a) operands down to 2^-100 keep full fp32 accuracy (the third piece is still a
+    normal bf16 number); below that pieces become bf16 SUBNORMALS, which the matrix pipe flushes to zero: at 2^-120 the second and third piece
+    are gone and the result is the bf16-rounded operand (measured 1.2e-4, bound 2^-8 relative, no NaN) -- magnitudes (1e-36) no activation,
+    weight or gradient of this path comes near; (b) an infinite
+    operand gives NaN (inf - inf inside the split) where an fp32 product gives inf; (c) NaN stays NaN; (d) zeros and signed zeros give 0"""
+    n = 64
+    eye = torch.eye(n, device=dev)
+
+    def through(m):
+        out = torch.empty(n, n, device=dev)
+        FF.gemm_raw(FF._p(eye), FF._p(m), FF._p(out), n, n, n, (n, 1), (n, 1), (n, 1))
+        return out
+
+    torch.manual_seed(0)
+    small = (torch.rand(n, n, device=dev) + 0.5) * 2.0 ** -100
+    assert torch.equal(through(small), small)
+    tiny = (torch.rand(n, n, device=dev) + 0.5) * 2.0 ** -120
+    t = through(tiny)
+    assert torch.isfinite(t).all() and float(((t - tiny).abs() / tiny).max()) <= 2.0 ** -8
+    m = torch.randn(n, n, device=dev)
+    m[3, 5] = float("inf")
+    m[7, 9] = float("nan")
+    m[0, 0], m[1, 1] = 0.0, -0.0
+    o = through(m)
+    assert torch.isnan(o[3, 5]) and torch.isnan(o[7, 9]) and float(o[0, 0]) == 0.0 and float(o[1, 1]) == 0.0
+    keep = torch.ones(n, n, dtype=torch.bool, device=dev)
+    keep[3, :] = False  # the identity row that multiplies the inf spreads NaN along its output row only
+    keep[7, :] = False
+    keep[:, 5] = False
+    keep[:, 9] = False
+    assert torch.equal(o[keep], m[keep])

@@ -147,6 +147,27 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert c.fmi_upfirdn2d_f32(p, p, p, 1, 2, 2, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == BAD                     # output would be empty
     c.fmi_avgpool_f32.argtypes = [vp, vp] + [ctypes.c_int] * 5 + [vp]
     assert c.fmi_avgpool_f32(p, p, 1, 4, 4, 4, 8, None) == BAD                                                 # window larger than the image
+    # piece images: a weight whose shape the preparation kernel cannot cut into pieces must be refused, not left uninitialised
+    we = _lib.WeightEntry(w=ctypes.addressof(buf), wf=ctypes.addressof(buf), wt=ctypes.addressof(buf), rows=16, C=16, taps=49, iters=0,
+                          wf3=ctypes.addressof(buf))
+    c.fmi_weight_prepare_f32.argtypes = [ctypes.POINTER(_lib.WeightEntry), ctypes.c_int, vp]
+    assert c.fmi_weight_prepare_f32(ctypes.byref(we), 1, None) == UNSUP                                         # 7 x 7 taps: no 8-channel group fits a tile
+    we2 = _lib.WeightEntry(w=ctypes.addressof(buf), wf=ctypes.addressof(buf), wt=ctypes.addressof(buf), rows=12, C=16, taps=9, iters=0,
+                           wt3=ctypes.addressof(buf))
+    assert c.fmi_weight_prepare_f32(ctypes.byref(we2), 1, None) == UNSUP                                        # rows % 8 != 0
+    c.fmi_split3_f32.argtypes = [vp, vp, vp, i64, ctypes.c_int, ctypes.c_int, f32, vp]
+    assert c.fmi_split3_f32(p, p, None, 4, 24, 0, 0.0, None) == BAD                                            # channels % 16 != 0
+    assert c.fmi_split3_f32(p, p, None, 4, 16, 5, 0.0, None) == BAD                                            # unknown op
+    d16 = _lib.ConvDesc(N=1, H=8, W=8, C=16, OH=8, OW=8, K=24, x_cstride=16, y_cstride=24, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    d16.y3 = ctypes.addressof(buf)
+    assert c.fmi_conv2d_fwd_f32(ctypes.byref(d16), p, p, None, None, p, 0, 1, 0, None) == BAD                  # piece image of a 24-channel result
+    c.fmi_resample_u8.argtypes = [vp, vp] + [ctypes.c_int] * 8 + [vp, vp, ctypes.c_int, vp]
+    assert c.fmi_resample_u8(p, p, 1, 8, 8, 3, 4, 2, 0, 8, p, p, 5, None) == BAD                               # axis must be 0 or 1
+    assert c.fmi_resample_u8(p, p, 1, 8, 8, 3, 4, 0, 4, 8, p, p, 5, None) == BAD                               # rows beyond the image
+    c.fmi_ssim_valid_f32.argtypes = [vp, vp, vp] + [ctypes.c_int] * 4 + [f32, f32, vp, vp, i64, vp]
+    assert c.fmi_ssim_valid_f32(p, p, p, 11, 1, 8, 8, 1e-4, 9e-4, p, p, 128, None) == BAD                      # image smaller than the window
+    c.fmi_adam_step_dev_guarded_f32.argtypes = [vp, ctypes.c_int] + [f32] * 5 + [vp, vp, vp]
+    assert c.fmi_adam_step_dev_guarded_f32(None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, p, None) == BAD
 
 
 def test_pmc_traffic_profile_is_current():
