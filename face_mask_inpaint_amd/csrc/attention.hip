@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(const float* __restric
                                                           const float* __restrict__ v2, const float* __restrict__ g1,
                                                           const float* __restrict__ g2, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, float* __restrict__ gv1,
-                                                          float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+                                                          float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2, int kb0) {
   constexpr int CT = NCT * 32, CW = CT / 4, NCW = CW / 32, DW = D / 4;
   constexpr int LDV = CT + 1, LDQ = D + 1;
   constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(const float* __restric
   float* dsT = EX + 4 * 2 * 1024;     // [2][32][33]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int n = blockIdx.y, j0 = blockIdx.x * 32;
+  const int n = blockIdx.y, j0 = ((int)blockIdx.x + kb0) * 32;  // kb0: key-block offset of this launch (reproducible mode: one key block per launch)
   const float* qb = q + (int64_t)n * T * D;
   const float* v1b = v1 + (int64_t)n * T * C1;
   const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
@@ -610,6 +610,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(const float* __restric
     __syncthreads();
   }
 
+  // all query-side atomics of this workgroup have COMPLETED before its key-side ones start: where both touch one row (the last query
+  // tile of the last key block) their order is then fixed, which the reproducible mode relies on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // ---- epilogue: dV rows (plain stores, this workgroup is their only writer) and the key-side dQ (atomics)
   {
     const int64_t row = (int64_t)n * T + j0 + l31;
@@ -644,7 +648,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
                                                            const float* __restrict__ v2, const float* __restrict__ g1,
                                                            const float* __restrict__ g2, const float* __restrict__ lse,
                                                            const float* __restrict__ delta, float* __restrict__ gv1,
-                                                           float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+                                                           float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2, int kb0) {
   constexpr int CT = NCT * 32, LDV = CT + 1, LDQ = D + 1, NDT = D / 32;
   constexpr int NQL = (8 * D) / 256 > 0 ? (8 * D) / 256 : 1, NVL = (8 * CT) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -657,7 +661,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
   float* RB = dsT + 4 * 32 * 33;       // [4][NDT][16][64] query-side partial tiles, summed over the four key blocks
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int n = blockIdx.y, j0 = blockIdx.x * 128 + wid * 32;   // this wave's keys
+  const int n = blockIdx.y, j0 = ((int)blockIdx.x + kb0) * 128 + wid * 32;   // this wave's keys (kb0: key-block offset of this launch)
   const float* qb = q + (int64_t)n * T * D;
   const float* v1b = v1 + (int64_t)n * T * C1;
   const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
@@ -795,6 +799,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
     __syncthreads();
   }
 
+  // all query-side atomics of this workgroup have COMPLETED before its key-side ones start: where both touch one row (the last query
+  // tile of the last key block) their order is then fixed, which the reproducible mode relies on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // ---- epilogue: dV rows of this wave's keys (plain stores) and the key-side dQ (atomics)
   const int64_t row = (int64_t)n * T + j0 + l31;
 #pragma unroll
@@ -840,7 +848,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
                                                               const float* __restrict__ v2, const float* __restrict__ g1,
                                                               const float* __restrict__ g2, const float* __restrict__ lse,
                                                               const float* __restrict__ delta, float* __restrict__ gv1,
-                                                              float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2) {
+                                                              float* __restrict__ gv2, float* __restrict__ gq, int T, int C1, int C2, int kb0) {
   constexpr int CT = NCT * 32, LDQ = D + 1, NDT = D / 32;
   constexpr int GLO = FULL ? 0 : DVLO * 32, GN = FULL ? CT : DVN * 32;   // gO channels staged per query tile
   constexpr int HOIST_V = FULL && 2 * DVN <= NCT;                        // room for the V pieces in registers
@@ -864,7 +872,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem_b;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const int n = blockIdx.y, j0 = blockIdx.x * 128 + wid * 32;   // this wave's keys
+  const int n = blockIdx.y, j0 = ((int)blockIdx.x + kb0) * 128 + wid * 32;   // this wave's keys (kb0: key-block offset of this launch)
   const float* qb = q + (int64_t)n * T * D;
   const float* v1b = v1 + (int64_t)n * T * C1;
   const float* v2b = v2 ? v2 + (int64_t)n * T * C2 : nullptr;
@@ -1138,6 +1146,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
     __syncthreads();
   }
 
+  // all query-side atomics of this workgroup have COMPLETED before its key-side ones start: where both touch one row (the last query
+  // tile of the last key block) their order is then fixed, which the reproducible mode relies on
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // ---- epilogue: dV rows of this wave's keys (plain stores) and the key-side dQ (atomics)
   const int64_t row = (int64_t)n * T + j0 + l31;
 #pragma unroll
@@ -1186,6 +1198,9 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
                      delta_scratch, rows);
   const int nct = (C1 + C2) / 32;
   const dim3 block(256);
+  // reproducible mode: the query-side tiles of dQ receive one atomic contribution per KEY BLOCK; launching the key blocks one after the
+  // other (stream order) fixes the order of those additions -- same kernels, grid.x = 1, key-block offset as an argument
+  const bool det = fmi_det();
   static const int bwd_dbg = getenv("FMI_ATT_BWD") ? atoi(getenv("FMI_ATT_BWD")) : 0;  // debug: 1 / 2 force a structure
   const bool small = (int64_t)(T / 128) * N < 128;  // short sequences: the first structure has 4x the workgroups
   if (T % 128 == 0 && bwd_dbg != 1 && (bwd_dbg == 2 || !small)) {  // second structure: one key block per wave, fragments in registers, 4x fewer atomics
@@ -1208,8 +1223,9 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
         return FMI_ERR_LAUNCH;                                                                                           \
       fmi_attr_mark(attr_setx, attr_setx_dev);                                                                                                  \
     }                                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>), grid2, block, lds2x(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
-                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+    for (int kb = 0; kb < (det ? (int)grid2.x : 1); ++kb)                                                                \
+      hipLaunchKernelGGL((attn_bwd2_x6_kernel<DD, NN, LO, CNT, FULLP>), det ? dim3(1, grid2.y) : grid2, block, lds2x(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
+                         (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2, kb);                                \
   } while (0)
 #define ATTB2_LAUNCH(DD, NN)                                                                                             \
   do {                                                                                                                   \
@@ -1229,8 +1245,9 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
         return FMI_ERR_LAUNCH;                                                                                           \
       fmi_attr_mark(attr_set2, attr_set2_dev);                                                                                                  \
     }                                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse,         \
-                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+    for (int kb = 0; kb < (det ? (int)grid2.x : 1); ++kb)                                                                \
+      hipLaunchKernelGGL((attn_bwd2_kernel<DD, NN>), det ? dim3(1, grid2.y) : grid2, block, lds2(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
+                         (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2, kb);                                \
     return fmi_launch_status();                                                                                          \
   } while (0)
     if (D == 64 && nct == 8) ATTB2_LAUNCH(64, 8);
@@ -1251,8 +1268,9 @@ extern "C" int fmi_attention_bwd_f32(const float* q, const float* v1, const floa
         return FMI_ERR_LAUNCH;                                                                                           \
       fmi_attr_mark(attr_set, attr_set_dev);                                                                                                   \
     }                                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd_kernel<DD, NN>), grid, block, lds_bytes(DD, NN * 32), st, q, v1, v2, go1, go2, lse,      \
-                       (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2);                                      \
+    for (int kb = 0; kb < (det ? (int)grid.x : 1); ++kb)                                                                 \
+      hipLaunchKernelGGL((attn_bwd_kernel<DD, NN>), det ? dim3(1, grid.y) : grid, block, lds_bytes(DD, NN * 32), st, q, v1, v2, go1, go2, lse, \
+                         (const float*)delta_scratch, gv1, gv2, gq_zeroed, T, C1, C2, kb);                                \
   } while (0)
   if (D == 64 && nct == 8) ATTB_LAUNCH(64, 8);
   else if (D == 32 && nct == 8) ATTB_LAUNCH(32, 8);

@@ -28,6 +28,9 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 
 #define FMI_WAVE 64
 
+extern "C" int fmi_deterministic_flag;  // misc.hip: reproducible mode (single-contributor reductions), see fmi_set_deterministic
+static inline bool fmi_det() { return fmi_deterministic_flag != 0; }
+
 static inline int fmi_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FMI_OK : FMI_ERR_LAUNCH;

@@ -63,7 +63,7 @@ static int conv_ksplit(int64_t M, int N, int K) {
 #else
   // keep the 128-wide tiles (operand reuse) and fill the chip by splitting the reduction instead of shrinking the tile
   const int64_t tiles = ceil_div64(M, 128) * ceil_div64(N, N <= 32 ? 32 : (N <= 64 ? 64 : 128));
-  if (K < 512) return 1;
+  if (K < 512 || fmi_det()) return 1;  // reproducible mode: no split reduction (partial sums would meet through atomics)
   static const int ks_dbg = getenv("FMI_KS") ? atoi(getenv("FMI_KS")) : 0;  // experiment: force the split
   if (ks_dbg > 0) return ks_dbg;
   if (tiles >= 320) {
@@ -393,6 +393,13 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
 #ifndef FMI_HOST_EMU
   if (batch_w == 1 && fmi_conv2d_thin_supported(d) && aligned16(x)) return fmi_conv2d_thin_wgrad_f32(d, x, dy, dwf, dbias, stream);
 #endif
+#ifndef FMI_HOST_EMU
+  // both operands as bf16 piece images (d->x3 = pieces of x, d->y3 = pieces of dy, INPUTS here): no split arithmetic, transposed LDS reads.
+  // The bias gradient does not ride along on this path (the caller runs fmi_bias_grad_f32).
+  static const bool wg3_off = getenv("FMI_WG3_OFF") != nullptr || getenv("FMI_P3_OFF") != nullptr;
+  if (!wg3_off && FMI_X6 && batch_w == 1 && !dbias && wgrad_p3_ok(d, d->x3, d->y3))
+    return launch_wgrad_p3(d, (const uint16_t*)d->x3, (const uint16_t*)d->y3, dwf, (hipStream_t)stream);
+#endif
   const int n_eff = batch_w > 1 ? 1 : d->N;
   ConvGeom g = fwd_geom(d, x, n_eff);
   // the bias gradient rides along as one extra output row (needs a float4-aligned row index and shared weights)
@@ -412,6 +419,7 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
   if (ksplit < 1) ksplit = 1;
   static const int wks_dbg = getenv("FMI_WKS") ? atoi(getenv("FMI_WKS")) : 0;  // experiment: force the pixel split of the weight gradient
   if (wks_dbg > 0) ksplit = wks_dbg;
+  if (fmi_det()) ksplit = 1;  // reproducible mode: one workgroup per tile walks the whole pixel reduction
   if (ksplit * batch_w > 65535) ksplit = 65535 / batch_w;
   return launch_gemm(la, lb, ep, Mg, Ng, Kg, batch_w, (int)ksplit, (hipStream_t)stream);
 }
@@ -484,6 +492,7 @@ extern "C" int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstrid
   // every workgroup ends with K atomics onto the same K addresses and those serialise: per training step (13 calls, up to 1 GB each)
   // 2048 workgroups took 1.31 ms, 512: 0.73, 256: 0.58 (the 1 GB tensor streams at 5.5 TB/s either way)
   if (blocks > 256) blocks = 256;
+  if (fmi_det()) blocks = 1;  // reproducible mode: one workgroup, one contribution per channel
   const int64_t rpb = ceil_div64(rows, blocks);
   blocks = ceil_div64(rows, rpb);
   const int K4 = K / 4;

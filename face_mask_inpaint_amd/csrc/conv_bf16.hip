@@ -349,7 +349,7 @@ static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws,
     if (set.ph[p].K > Kmax) Kmax = set.ph[p].K;
   }
   set.N = N;
-  const bool can_split = ws && ws_floats >= out_elems && out_elems % 4 == 0 && !set.ph[0].ep.colscale;
+  const bool can_split = ws && ws_floats >= out_elems && out_elems % 4 == 0 && !set.ph[0].ep.colscale && !fmi_det();  // reproducible mode: no split
 #define FMI_LAUNCH_B(TILE)                                                                                                        \
   do {                                                                                                                            \
     const int64_t tn = ceil_div64(N, TILE::BN);                                                                                   \
@@ -693,6 +693,7 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 65535) ksplit = 65535;
   if (ksplit >= 6) ksplit = (ksplit + 4) / 8 * 8;  // splits are dealt to the 8 XCDs in groups of 8: keep the groups full
+  if (fmi_det()) ksplit = 1;                       // reproducible mode
   a.kchunk = (int)(ceil_div64(ceil_div64(a.P, ksplit), 64) * 64);
   ksplit = ceil_div64(a.P, a.kchunk);
   a.tiles = (int)(tm * tn);

@@ -438,3 +438,218 @@ static int launch_conv3x3_p3(const C3P3Args& a, const ConvEp& ep, int M, int ksp
   return fmi_launch_status();
 }
 #endif
+
+#ifndef FMI_HOST_EMU
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient with both operands as pieces: dwf[tap][c][k] += sum over pixels x[pixel + tap][c] * dy[pixel][k].
+// The reduction index (pixels) is the SLOW index of both NHWC piece images, so the MFMA operands come from ds_read_b64_tr_b16 (the
+// hardware 4 x 16 transpose), as in the bf16 weight gradient (conv_bf16.hip): LDS image of one (operand, piece, 32-row group) =
+// [16 pixels][32 rows] bf16 = 1 KiB = ONE wave instruction of the copy (lane = pixel * 4 + 8-channel chunk), so all copies of a thread
+// share one pixel decode per stage; a stage is one 16-pixel k-step.  Pixel splits over workgroups meet through fp32 atomics; a split is
+// pinned to one XCD (its tiles re-read the same pixels through that XCD's L2).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short p3_s16x4 __attribute__((ext_vector_type(4)));
+struct WgP3Args {
+  const uint16_t* x3;
+  const uint16_t* dy3;
+  float* dwf;
+  ConvGeom g;  // forward geometry: anchors = output pixels, all kh*kw taps
+  int Kout, Mrows, P, kchunk;
+  int tiles, ksplit, xcd_splits;
+};
+
+template <class T>
+__global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int tiles_n) {
+  constexpr int BM = T::BM, BN = T::BN, BK = 16, NW = T::NW;
+  constexpr int GA = BM / 32, GB = BN / 32;       // 32-row groups per operand tile
+  constexpr int NI = 3 * (GA + GB);               // wave instructions per stage
+  constexpr int NL = (NI + NW - 1) / NW;
+  constexpr int STAGE = NI * 1024;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int lid, split;
+  if (a.xcd_splits) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int grp = idx / a.tiles;
+    lid = idx - grp * a.tiles;
+    split = grp * 8 + xcd;
+    if (split >= a.ksplit) return;
+  } else {
+    lid = xcd_remap(blockIdx.x, gridDim.x);
+    split = blockIdx.y;
+  }
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wm = (wid / T::WN) * T::TM * 32, wn = (wid % T::WN) * T::TN * 32;
+  const ConvGeom& g = a.g;
+  const int k_begin = split * a.kchunk;
+  int k_end = k_begin + a.kchunk;
+  if (k_end > a.P) k_end = a.P;
+
+  // copy slot j of this wave = instruction j * NW + wid of [A: 3 pieces x GA groups][B: 3 pieces x GB groups]
+  const int pl = lane >> 2, cq = lane & 3;  // pixel of the k-step, 8-channel chunk of the 32-row group
+  int s_dy[NL], s_dx[NL];                   // A slots: tap displacement (dy far outside = no copy); B slots: dy = 0x40000000 marks them
+  int64_t s_off[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int ii = j * NW + wid;
+    s_dy[j] = -0x20000000, s_dx[j] = 0, s_off[j] = 0;
+    if (ii < 3 * GA) {
+      const int piece = ii / GA, gr = ii - piece * GA;
+      const int row = m0 + 32 * gr;  // (tap, channel) row: a group of 32 rows lies inside one tap (C % 32 == 0)
+      if (row < a.Mrows) {
+        const int t = (int)fdiv((uint32_t)row, g.dC);
+        const int i = (int)fdiv((uint32_t)t, g.dntx), jx = t - i * g.ntx;
+        const int ch = row - t * g.C + 8 * cq;
+        s_dy[j] = g.dy0 + g.ystep * i;
+        s_dx[j] = g.dx0 + g.xstep * jx;
+        s_off[j] = ((int64_t)s_dy[j] * g.IW + s_dx[j]) * (3 * g.C) + (ch >> 4) * 48 + piece * 16 + ((ch >> 3) & 1) * 8;
+      }
+    } else if (ii < NI) {
+      const int q = ii - 3 * GA, piece = q / GB, gr = q - piece * GB;
+      const int col = n0 + 32 * gr + 8 * cq;
+      s_dy[j] = col < a.Kout ? 0x40000000 : -0x20000000;
+      s_off[j] = (col >> 4) * 48 + piece * 16 + ((col >> 3) & 1) * 8;
+    }
+  }
+  const int n_w = (NI - wid + NW - 1) / NW;
+
+  f32x16 acc[T::TM][T::TN];
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto issue = [&](int k0, int st) __attribute__((always_inline)) {
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + wid * 1024));
+    const int pix = k0 + pl;
+    const bool pv = pix < k_end;
+    const uint32_t n = fdiv((uint32_t)pix, g.dG);
+    const uint32_t rem = (uint32_t)pix - n * (uint32_t)(g.GH * g.GW);
+    const uint32_t gy = fdiv(rem, g.dGW);
+    const uint32_t gx = rem - gy * (uint32_t)g.GW;
+    const int iy0 = (int)gy * g.S, ix0 = (int)gx * g.S;
+    const int64_t xb = ((int64_t)((int)n * g.IH + iy0) * g.IW + ix0) * (3 * g.C);
+    const int64_t yb = (int64_t)pix * (3 * a.Kout);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (j >= n_w) break;
+      const void* gp;
+      if (s_dy[j] == 0x40000000) {
+        gp = pv ? (const void*)(a.dy3 + yb + s_off[j]) : (const void*)fmi_chunk_zero;
+      } else {
+        const bool ok = pv && (unsigned)(iy0 + s_dy[j]) < (unsigned)g.IH && (unsigned)(ix0 + s_dx[j]) < (unsigned)g.IW;
+        gp = ok ? (const void*)(a.x3 + xb + s_off[j]) : (const void*)fmi_chunk_zero;
+      }
+      glds16_p3(gp, s0 + (uint32_t)(j * NW * 1024));
+    }
+  };
+  // transposed fragment read of one [16 pixels][32 rows] image: lane 4q+p of a 16-lane group addresses pixel row q, rows 4p..4p+3 of
+  // the group's 16; the second read covers pixels +4 (256 bytes on)
+  const int i16 = lane & 15;
+  const uint32_t lbase = (uint32_t)((8 * lh + (i16 >> 2)) * 64 + 32 * ((lane >> 4) & 1) + 8 * (i16 & 3));
+  auto frag = [&](uint32_t img) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) p3_s16x4* lp;
+    const uint32_t ad = img + lbase;
+    union {
+      p3_s16x4 h[2];
+      bf16x8_t v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)ad);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(ad + 256u));
+    return u.v;
+  };
+  auto compute = [&](int st) __attribute__((always_inline)) {
+    const uint32_t sa = lds0 + (uint32_t)(st * STAGE), sb = sa + 3 * GA * 1024;
+    bf16x8_t pa[T::TM][3], pb[T::TN][3];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) pa[i][pc] = frag(sa + (uint32_t)((pc * GA + wm / 32 + i) * 1024));
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) pb[j][pc] = frag(sb + (uint32_t)((pc * GB + wn / 32 + j) * 1024));
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = mfma_x6(pa[i], pb[j], acc[i][j]);
+  };
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  if (nt > 0) issue(k_begin, 0);
+  int st = 0;
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) issue(k_begin + (t + 1) * BK, st ^ 1);
+    compute(st);
+    st ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= a.Mrows) continue;
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) {
+        const int col = n0 + wn + j * 32 + l31;
+        if (col < a.Kout) atomicAdd(a.dwf + (int64_t)row * a.Kout + col, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+using WG3_128x128 = P3Tile<2, 2, 2, 2>;
+using WG3_128x64 = P3Tile<2, 2, 2, 1>;
+using WG3_128x32 = P3Tile<4, 1, 1, 1>;
+using WG3_256x128 = P3Tile<4, 2, 2, 2>;  // 8 waves
+
+// x3 / dy3: piece images of x [N][H][W][C] and dy [N][OH][OW][K] (dense tensors)
+static int launch_wgrad_p3(const fmi_conv_desc* d, const uint16_t* x3, const uint16_t* dy3, float* dwf, hipStream_t st) {
+  WgP3Args a{};
+  a.x3 = x3; a.dy3 = dy3; a.dwf = dwf;
+  ConvGeom& g = a.g;
+  const int dl = d->dil > 1 ? d->dil : 1;
+  g.N = d->N; g.IH = d->H; g.IW = d->W; g.C = d->C; g.cstride = d->C;
+  g.GH = d->OH; g.GW = d->OW; g.S = d->stride;
+  g.nty = d->kh; g.ntx = d->kw; g.dy0 = -d->pad; g.dx0 = -d->pad; g.ystep = dl; g.xstep = dl;
+  g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
+  g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
+  a.Kout = d->K; a.Mrows = d->kh * d->kw * d->C; a.P = d->N * d->OH * d->OW;
+  static const int tile_dbg = getenv("FMI_WG3_TILE") ? atoi(getenv("FMI_WG3_TILE")) : 0;  // experiment: 1 = the 8-wave 256 x 128 tile
+  const bool big = tile_dbg == 1 && d->K > 64;
+  const int bm = big ? 256 : 128;
+  const int bn = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);
+  const int64_t tm = ceil_div64(a.Mrows, bm), tn = ceil_div64(d->K, bn);
+  int64_t ksplit = 2048 / (tm * tn);
+  const int64_t kmax = a.P / 512;
+  if (ksplit > kmax) ksplit = kmax;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 65535) ksplit = 65535;
+  if (ksplit >= 6) ksplit = (ksplit + 4) / 8 * 8;  // splits are dealt to the 8 XCDs in groups of 8: keep the groups full
+  if (fmi_det()) ksplit = 1;                       // reproducible mode
+  a.kchunk = (int)(ceil_div64(ceil_div64(a.P, ksplit), 16) * 16);
+  ksplit = ceil_div64(a.P, a.kchunk);
+  a.tiles = (int)(tm * tn);
+  a.ksplit = (int)ksplit;
+  a.xcd_splits = ksplit >= 8 ? 1 : 0;
+  const int64_t nwg = a.xcd_splits ? tm * tn * ceil_div64(ksplit, 8) * 8 : tm * tn;
+  if (nwg > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)nwg, a.xcd_splits ? 1u : (unsigned)ksplit);
+  if (big) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_256x128>), grid, dim3(512), 0, st, a, (int)tn);
+  else if (bn == 32) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x32>), grid, dim3(256), 0, st, a, (int)tn);
+  else if (bn == 64) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x64>), grid, dim3(256), 0, st, a, (int)tn);
+  else hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x128>), grid, dim3(256), 0, st, a, (int)tn);
+  return fmi_launch_status();
+}
+static bool wgrad_p3_ok(const fmi_conv_desc* d, const void* x3, const void* dy3) {
+  return x3 && dy3 && d->C % 32 == 0 && d->K % 16 == 0 && d->x_cstride == d->C && d->y_cstride == d->K && d->pad_mode == 0 && ((uintptr_t)x3 & 15) == 0 &&
+         ((uintptr_t)dy3 & 15) == 0 && (int64_t)d->N * d->H * d->W * 3 * d->C < (1ll << 40) && (int64_t)d->N * d->OH * d->OW < 0x7fffffffLL;
+}
+#endif

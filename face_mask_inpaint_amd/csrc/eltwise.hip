@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ a, c
 }
 extern "C" int fmi_dot_f32(const float* a, const float* b, int64_t n, float scale, float* out, void* stream) {
   if (!a || !b || !out || n <= 0) return FMI_ERR_BAD_ARG;
-  int grid = fmi_bw_grid(n, 256 * 8);
+  int grid = fmi_det() ? 1 : fmi_bw_grid(n, 256 * 8);
   hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, n, scale, out);
   return fmi_launch_status();
 }
@@ -369,12 +369,15 @@ template <typename T>
 __global__ void __launch_bounds__(256) bias_grad_nchw_kernel(const T* __restrict__ g, int N, int C, int64_t HW,
                                                              float* __restrict__ dbias) {
   __shared__ float red[4];
-  const int c = blockIdx.x % C, n = blockIdx.x / C;
-  const T* p = g + ((int64_t)n * C + c) * HW;
-  float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.y * 256) s += bg_load(p, i);
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) atomicAdd(dbias + c, s);
+  // block x = (sample, channel); reproducible mode launches C blocks that walk the samples in order (gridDim.x == C, one block in y)
+  const int c = blockIdx.x % C;
+  for (int n = blockIdx.x / C; n < N; n += gridDim.x / C) {
+    const T* p = g + ((int64_t)n * C + c) * HW;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.y * 256) s += bg_load(p, i);
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(dbias + c, s);
+  }
 }
 template <typename T>
 static int bias_grad_nchw_launch(const T* g, int N, int C, int64_t HW, float* dbias, void* stream) {
@@ -382,7 +385,8 @@ static int bias_grad_nchw_launch(const T* g, int N, int C, int64_t HW, float* db
   int gy = (int)((HW + 256 * 16 - 1) / (256 * 16));
   if (gy < 1) gy = 1;
   if (gy > 64) gy = 64;
-  hipLaunchKernelGGL(bias_grad_nchw_kernel<T>, dim3(N * C, gy), dim3(256), 0, (hipStream_t)stream, g, N, C, HW, dbias);
+  const dim3 grid = fmi_det() ? dim3(C, 1) : dim3(N * C, gy);
+  hipLaunchKernelGGL(bias_grad_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, g, N, C, HW, dbias);
   return fmi_launch_status();
 }
 extern "C" int fmi_bias_grad_nchw_f32(const float* g, int N, int C, int64_t HW, float* dbias, void* stream) {

@@ -30,7 +30,7 @@ static int run(const LA& la, const LB& lb, float* C, int M, int N, int K, int64_
   // ... and so would the M = batch-size products of EqualLinear (16 x 512 x 512: 4 tiles walking 32 reduction tiles one after
   // the other, 22 us per launch, 66 launches in a decoder step): a few reduction tiles per workgroup there
   const bool tiny = M <= 32 && tiles < 32 && K >= 256 && K < 2048;
-  if ((tiles < 192 && K >= 2048) || tiny) {
+  if (((tiles < 192 && K >= 2048) || tiny) && !fmi_det()) {  // reproducible mode: no split reduction
     int64_t ks = tiny ? 128 / tiles : 768 / tiles;
     const int64_t kmin = tiny ? 64 : 512;
     if (ks > K / kmin) ks = K / kmin;

@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) reduce_loss_kernel(const float* __restric
 extern "C" int fmi_reduce_loss_f32(int kind, const float* a, const float* b, int64_t n, float c0, float scale, float* out,
                                    void* stream) {
   if (!a || !out || n <= 0 || (kind != 2 && !b)) return FMI_ERR_BAD_ARG;
-  const int grid = fmi_bw_grid(n, 256 * 16);
+  const int grid = fmi_det() ? 1 : fmi_bw_grid(n, 256 * 16);  // reproducible mode: one block, one contribution
   hipStream_t st = (hipStream_t)stream;
   if (kind == 0) hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(grid), dim3(256), 0, st, a, b, n, c0, scale, out);
   else if (kind == 1) hipLaunchKernelGGL((reduce_loss_kernel<1>), dim3(grid), dim3(256), 0, st, a, b, n, c0, scale, out);
@@ -89,6 +89,7 @@ extern "C" int fmi_cx_channel_mean_f32(const float* y, float* mu, int64_t rows, 
   if (!y || !mu || rows <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
   int64_t blocks = ceil_div64(rows, 64);
   if (blocks > 1024) blocks = 1024;
+  if (fmi_det()) blocks = 1;
   const int64_t rpb = ceil_div64(rows, blocks);
   blocks = ceil_div64(rows, rpb);
   hipLaunchKernelGGL(col_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, mu, rows, C, rpb,
@@ -232,19 +233,20 @@ extern "C" int fmi_cx_cols_f32(const float* cxij, float* colmax, int* colarg, in
 __global__ void __launch_bounds__(256) cx_loss_kernel(const float* __restrict__ colmax, float* __restrict__ cx,
                                                       float* __restrict__ loss, int N, int P, float scale) {
   __shared__ float red[4];
-  const int n = blockIdx.x;
-  float s = 0.f;
-  for (int j = threadIdx.x; j < P; j += 256) s += colmax[(int64_t)n * P + j];
-  s = block_sum_256(s, red);
-  if (threadIdx.x == 0) {
-    const float c = s / (float)P;
-    cx[n] = c;
-    atomicAdd(loss, scale * (-logf(c + 1e-5f)) / (float)N);
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {  // one sample per block; all samples in order in reproducible mode (grid = 1)
+    float s = 0.f;
+    for (int j = threadIdx.x; j < P; j += 256) s += colmax[(int64_t)n * P + j];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+      const float c = s / (float)P;
+      cx[n] = c;
+      atomicAdd(loss, scale * (-logf(c + 1e-5f)) / (float)N);
+    }
   }
 }
 extern "C" int fmi_cx_loss_f32(const float* colmax, float* cx, float* loss, int N, int P, float scale, void* stream) {
   if (!colmax || !cx || !loss || N <= 0 || P <= 0) return FMI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(cx_loss_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, colmax, cx, loss, N, P, scale);
+  hipLaunchKernelGGL(cx_loss_kernel, dim3(fmi_det() ? 1 : N), dim3(256), 0, (hipStream_t)stream, colmax, cx, loss, N, P, scale);
   return fmi_launch_status();
 }
 
@@ -295,12 +297,13 @@ extern "C" int fmi_cx_bwd_f32(const float* cxij, const float* dmin, const int* a
 // per (plane, pixel) ssim value summed into out[plane_group] with fp64 block sums.  Metric only (no gradient).
 __global__ void __launch_bounds__(256) ssim_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                    const float* __restrict__ g, int ws, int H, int W, int planes_per_out,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, int planes) {
   __shared__ double red[4];
   __shared__ float sg[64];
   if (threadIdx.x < ws) sg[threadIdx.x] = g[threadIdx.x];
   __syncthreads();
-  const int plane = blockIdx.y, half = ws / 2;
+  const int half = ws / 2;
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {  // one plane per block row; all planes in order in reproducible mode
   const float* pa = a + (int64_t)plane * H * W;
   const float* pb = b + (int64_t)plane * H * W;
   double acc = 0.0;
@@ -328,6 +331,8 @@ __global__ void __launch_bounds__(256) ssim_kernel(const float* __restrict__ a, 
   }
   acc = block_sum_256_d(acc, red);
   if (threadIdx.x == 0) atomicAdd(out + plane / planes_per_out, (float)acc);
+  __syncthreads();
+  }
 }
 extern "C" int fmi_ssim_f32(const float* img1, const float* img2, const float* window1d, int ws, int planes, int H, int W,
                             int planes_per_out, float* out_zeroed, void* stream) {
@@ -336,8 +341,8 @@ extern "C" int fmi_ssim_f32(const float* img1, const float* img2, const float* w
     return FMI_ERR_BAD_ARG;
   int gx = (H * W + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(ssim_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, img1, img2, window1d, ws, H, W,
-                     planes_per_out, out_zeroed);
+  const dim3 grid = fmi_det() ? dim3(1, 1) : dim3(gx, planes);
+  hipLaunchKernelGGL(ssim_kernel, grid, dim3(256), 0, (hipStream_t)stream, img1, img2, window1d, ws, H, W, planes_per_out, out_zeroed, planes);
   return fmi_launch_status();
 }
 
@@ -410,7 +415,7 @@ extern "C" int fmi_lpips_layer_f32(const float* fx, const float* fy, const float
                                    void* stream) {
   if (!fx || !fy || !w || !out || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
   const int64_t total = pixels * C;
-  int g = fmi_bw_grid(total, 256 * 8);
+  int g = fmi_det() ? 1 : fmi_bw_grid(total, 256 * 8);
   hipLaunchKernelGGL(lpips_layer_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, fx, fy, w, out, total, C, scale);
   return fmi_launch_status();
 }

@@ -166,7 +166,7 @@ static void launch_in_reduce(const T* x, const T* gy, const float* stats, const 
     hipLaunchKernelGGL(sum_parts_f64_kernel, dim3((C * 2 + 63) / 64, N), dim3(1024), 0, st, (const double*)ws, sums, blocks, C * 2);
     return;
   }
-  const int rpb = rows_per_block(N, HW, 2048, 512);
+  const int rpb = fmi_det() ? HW : rows_per_block(N, HW, 2048, 512);  // reproducible mode: one block per sample, one contribution per address
   hipLaunchKernelGGL((in_reduce_kernel<MODE, T>), dim3((HW + rpb - 1) / rpb, N), dim3(256), 0, st, x, gy, stats, gamma, beta, sums, HW, C, slope,
                      rpb, 0);
 }

@@ -115,6 +115,7 @@ extern "C" int fmi_avgpool_f32(const float* x, float* y, int N, int H, int W, in
       const int64_t HW = (int64_t)H * W;
       int64_t blocks = ceil_div64(HW, 128);
       if (blocks * N > 2048) blocks = ceil_div64(2048, N);
+      if (fmi_det()) blocks = 1;  // reproducible mode: one block per image
       const int64_t rpb = ceil_div64(HW, blocks);
       blocks = ceil_div64(HW, rpb);
       if (hipMemsetAsync(y, 0, (size_t)N * C * sizeof(float), (hipStream_t)stream) != hipSuccess) return FMI_ERR_LAUNCH;
@@ -251,6 +252,55 @@ __global__ void __launch_bounds__(256) resize_bwd_kernel(const float* __restrict
     atomicAdd(b + ((int64_t)ly.i1 * W + lx.i1) * C, ly.l1 * lx.l1 * g);
   }
 }
+// reproducible form of the adjoint: every INPUT pixel gathers from the output pixels whose interpolation footprint contains it, in a
+// fixed order (gx is written, not accumulated).  Candidates: outputs around i / scale, tested with the forward's own lerp_of.
+__device__ __forceinline__ void resize_cands(int i, int in, int out, int& lo, int& hi) {
+  const float inv = in > 1 ? (float)(out - 1) / (float)(in - 1) : 0.f;
+  lo = (int)((float)(i - 1) * inv) - 2;
+  hi = (int)((float)(i + 1) * inv) + 2;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+__global__ void __launch_bounds__(256) resize_bwd_gather_kernel(const float* __restrict__ gy, float* __restrict__ gx, int H, int W, int C,
+                                                                int OH, int OW, const float* __restrict__ stdv, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    int ylo, yhi, xlo, xhi;
+    resize_cands(iy, H, OH, ylo, yhi);
+    resize_cands(ix, W, OW, xlo, xhi);
+    const float* b = gy + (int64_t)n * OH * OW * C + c;
+    float s = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const Lerp ly = lerp_of(oy, H, OH);
+      const float wy = (ly.i0 == iy ? ly.l0 : 0.f) + (ly.i1 == iy ? ly.l1 : 0.f);
+      if (ly.i0 != iy && ly.i1 != iy) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const Lerp lx = lerp_of(ox, W, OW);
+        if (lx.i0 != ix && lx.i1 != ix) continue;
+        const float wx = (lx.i0 == ix ? lx.l0 : 0.f) + (lx.i1 == ix ? lx.l1 : 0.f);
+        float g = b[((int64_t)oy * OW + ox) * C];
+        if (stdv) g = g / stdv[c];
+        // the scatter form adds l_y * l_x * g per corner; a pixel that is BOTH corners of an axis (the clamped last row) gets both weights
+        if (ly.i0 == iy && ly.i1 == iy) {
+          if (lx.i0 == ix) s += ly.l0 * lx.l0 * g + ly.l1 * lx.l0 * g;
+          if (lx.i1 == ix) s += ly.l0 * lx.l1 * g + ly.l1 * lx.l1 * g;
+        } else {
+          const float w1 = ly.i0 == iy ? ly.l0 : ly.l1;
+          if (lx.i0 == ix) s += w1 * lx.l0 * g;
+          if (lx.i1 == ix) s += w1 * lx.l1 * g;
+        }
+        (void)wx;
+        (void)wy;
+      }
+    }
+    gx[i] = s;
+  }
+}
 extern "C" int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, int W, int C, int OH, int OW,
                                        const float* ch_mean, const float* ch_std, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
@@ -263,6 +313,11 @@ extern "C" int fmi_resize_bilinear_f32(const float* x, float* y, int N, int H, i
 extern "C" int fmi_resize_bilinear_bwd_f32(const float* gy, float* gx, int N, int H, int W, int C, int OH, int OW,
                                            const float* ch_std, void* stream) {
   if (!gy || !gx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return FMI_ERR_BAD_ARG;
+  if (fmi_det()) {  // reproducible mode: gather form (gx overwritten)
+    const int64_t tin = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(resize_bwd_gather_kernel, dim3(fmi_bw_grid(tin, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, C, OH, OW, ch_std, tin);
+    return fmi_launch_status();
+  }
   const int64_t total = (int64_t)N * OH * OW * C;
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, gx, H, W, C, OH,
                      OW, ch_std, total);
@@ -386,6 +441,32 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* __restric
     atomicAdd(gx + (((int64_t)n * H + oy * stride + bi / k) * W + ox * stride + bi % k) * C + c, gy[i]);
   }
 }
+// reproducible form: every input pixel gathers from the windows that selected it, in a fixed order (gx written, not accumulated)
+__global__ void __launch_bounds__(256) maxpool_bwd_gather_kernel(const float* __restrict__ gy, const int32_t* __restrict__ arg,
+                                                                 float* __restrict__ gx, int H, int W, int C, int OH, int OW, int k, int stride,
+                                                                 int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    int oy0 = (y - k + stride) / stride, ox0 = (x - k + stride) / stride;  // ceil((y - k + 1) / stride) for y - k + 1 > 0
+    if (y - k + 1 <= 0) oy0 = 0;
+    if (x - k + 1 <= 0) ox0 = 0;
+    int oy1 = y / stride, ox1 = x / stride;
+    if (oy1 > OH - 1) oy1 = OH - 1;
+    if (ox1 > OW - 1) ox1 = OW - 1;
+    float s = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const int64_t o = (((int64_t)n * OH + oy) * OW + ox) * C + c;
+        if (arg[o] == (y - oy * stride) * k + (x - ox * stride)) s += gy[o];
+      }
+    gx[i] = s;
+  }
+}
 extern "C" int fmi_maxpool_f32(const float* x, float* y, int32_t* argmax, int N, int H, int W, int C, int k, int stride, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || k <= 0 || stride <= 0 || H < k || W < k) return FMI_ERR_BAD_ARG;
   const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
@@ -398,6 +479,12 @@ extern "C" int fmi_maxpool_bwd_f32(const float* gy, const int32_t* argmax, float
   if (!gy || !argmax || !gx || N <= 0 || C <= 0 || k <= 0 || stride <= 0 || H < k || W < k) return FMI_ERR_BAD_ARG;
   const int OH = (H - k) / stride + 1, OW = (W - k) / stride + 1;
   const int64_t total = (int64_t)N * OH * OW * C;
+  if (fmi_det()) {  // reproducible mode: gather form
+    const int64_t tin = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3(fmi_bw_grid(tin, 256)), dim3(256), 0, (hipStream_t)stream, gy, argmax, gx, H, W, C, OH, OW, k,
+                       stride, tin);
+    return fmi_launch_status();
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(fmi_bw_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, gy, argmax, gx, H, W, C, OH, OW, k, stride, total);
   return fmi_launch_status();
 }

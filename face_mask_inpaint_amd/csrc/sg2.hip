@@ -115,6 +115,7 @@ extern "C" int fmi_scale_channels_gs_f32(const float* g, const float* x, float* 
   const int64_t want = ceil_div64(2048, N);
   if (parts && cap > want) cap = want;
   if (blocks > cap) blocks = cap;
+  if (fmi_det() && !parts) blocks = 1;  // reproducible mode without a partials workspace: one block per sample
   const int64_t rpb = ceil_div64(P, blocks);
   blocks = ceil_div64(P, rpb);
   hipLaunchKernelGGL(scale_channels_gs_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, g, x, parts ? ws : gs, P, C, rpb,
@@ -192,14 +193,14 @@ extern "C" int fmi_noise_bias_act_bwd_f32(const float* g, const float* y, const 
   if (!g || !y || !gx || pixels <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
   if (C % 4 == 0 && ((((uintptr_t)g) | ((uintptr_t)y) | ((uintptr_t)gx)) & 15) == 0) {
     const int64_t total4 = pixels * (C / 4);
-    int grid = fmi_bw_grid(total4, 256 * 4);
+    int grid = (fmi_det() && noise && gnw) ? 1 : fmi_bw_grid(total4, 256 * 4);  // reproducible mode: one block sums the noise-weight gradient
     if (grid > 1024) grid = 1024;  // one atomic per block on a single address
     hipLaunchKernelGGL(noise_bias_act_bwd_vec_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)y,
                        noise, (float4*)gx, gnw, total4, C / 4, alpha, scale);
     return fmi_launch_status();
   }
   const int64_t total = pixels * C;
-  hipLaunchKernelGGL(noise_bias_act_bwd_kernel, dim3(fmi_bw_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, y, noise,
+  hipLaunchKernelGGL(noise_bias_act_bwd_kernel, dim3((fmi_det() && noise && gnw) ? 1 : fmi_bw_grid(total, 256 * 4)), dim3(256), 0, (hipStream_t)stream, g, y, noise,
                      gx, gnw, total, C, alpha, scale);
   return fmi_launch_status();
 }
@@ -456,6 +457,7 @@ extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a,
     int64_t blocks = ceil_div64(rows, 64);
     const int64_t cap = parts ? (ws_floats / C < 1024 ? ws_floats / C : 1024) : 256;  // atomics on C addresses serialise: few blocks
     if (blocks > cap) blocks = cap;
+    if (fmi_det() && !parts) blocks = 1;  // reproducible mode without a partials workspace
     const int64_t rpb = ceil_div64(rows, blocks);
     blocks = ceil_div64(rows, rpb);
     hipLaunchKernelGGL(prelu_bwd_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)x,
@@ -465,6 +467,7 @@ extern "C" int fmi_prelu_bwd_f32(const float* g, const float* x, const float* a,
   }
   int64_t blocks = ceil_div64(rows, 128);
   if (blocks > 2048) blocks = 2048;
+  if (fmi_det()) blocks = 1;  // reproducible mode
   const int64_t rpb = ceil_div64(rows, blocks);
   blocks = ceil_div64(rows, rpb);
   hipLaunchKernelGGL(prelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, x, a, gx, ga, rows, C, rpb);

@@ -715,13 +715,13 @@ static int thin_wgrad_impl(const fmi_conv_desc* d, const float* x, float in_slop
     const int tiles_x = (d->W + LT_W - 1) / LT_W, tiles_y = (d->H + LT_H - 1) / LT_H;
     const int64_t nt = (int64_t)d->N * tiles_x * tiles_y;
     if (nt < (1ll << 31)) {
-      const int grid = nt < 768 ? (int)nt : 768;
+      const int grid = fmi_det() ? 1 : (nt < 768 ? (int)nt : 768);  // reproducible mode: one persistent workgroup walks every tile
       THIN_DISPATCH(thin_wgrad_lds_kernel, a, dwf, dbias, tiles_x, tiles_y, (int)nt);
       return fmi_launch_status();
     }
   }
   const int64_t waves = (total + 64 / G - 1) / (64 / G);
-  const int grid = (int)(waves / 4 > 1024 ? 1024 : (waves + 3) / 4);
+  const int grid = fmi_det() ? 1 : (int)(waves / 4 > 1024 ? 1024 : (waves + 3) / 4);
   THIN_DISPATCH(thin_wgrad_kernel, a, dwf, dbias, G, total);
   return fmi_launch_status();
 }

@@ -219,14 +219,16 @@ __global__ void __launch_bounds__(256) wg_dot_kernel(const GradArgs args, float*
   const fmi_weight_grad_entry e = args.e[blockIdx.y];
   if (!e.u) return;
   const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
-  const int64_t total = (int64_t)rows * width, base = (int64_t)blockIdx.x * PACK_PER_BLOCK;
-  if (base >= total) return;
+  const int64_t total = (int64_t)rows * width;
+  if ((int64_t)blockIdx.x * PACK_PER_BLOCK >= total) return;
   float s = 0.f;
-  for (int64_t o = base + threadIdx.x; o < base + PACK_PER_BLOCK && o < total; o += 256) {  // o indexes dwf: [tap][c][row]
-    const int r = (int)(o % rows);
-    const int64_t q = o / rows;
-    const int c = (int)(q % C), tap = (int)(q / C);
-    s += e.dwf[o] * e.w[(int64_t)r * width + c * taps + tap];
+  for (int64_t base = (int64_t)blockIdx.x * PACK_PER_BLOCK; base < total; base += (int64_t)gridDim.x * PACK_PER_BLOCK) {  // one chunk per block; ALL chunks in reproducible mode (grid.x = 1)
+    for (int64_t o = base + threadIdx.x; o < base + PACK_PER_BLOCK && o < total; o += 256) {  // o indexes dwf: [tap][c][row]
+      const int r = (int)(o % rows);
+      const int64_t q = o / rows;
+      const int c = (int)(q % C), tap = (int)(q / C);
+      s += e.dwf[o] * e.w[(int64_t)r * width + c * taps + tap];
+    }
   }
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) atomicAdd(dots + blockIdx.y, s);
@@ -287,7 +289,7 @@ extern "C" int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int cou
       if (t > max_t) max_t = t;
       if (a.e[i].u) any_sn = 1;
     }
-    const dim3 grid((unsigned)ceil_div64(max_t, PACK_PER_BLOCK), n);
+    const dim3 grid(fmi_det() ? 1u : (unsigned)ceil_div64(max_t, PACK_PER_BLOCK), n);  // reproducible mode: one block per tensor
     if (any_sn) hipLaunchKernelGGL(wg_dot_kernel, grid, dim3(256), 0, st, a, scratch_zeroed + base);
     int64_t max_tiles = 1;
     for (int i = 0; i < n; ++i) {

@@ -111,6 +111,23 @@ def _chk(*ts, dtype=torch.float32):
             raise FmiError("expected a contiguous tensor")
 
 
+class deterministic:
+    """``with FF.deterministic():`` -- the library's reproducible mode (include/fmi_hip.h: fmi_set_deterministic; FMI_DETERMINISTIC=1 sets it
+    for a whole process): single-contributor reductions instead of fp32 atomics from many workgroups, so two runs are bit-identical.
+    Slower; a checking mode."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _L().set_deterministic(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *exc):
+        _L().set_deterministic(self.prev)
+        return False
+
+
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """NCHW-shaped tensor -> NHWC contiguous (free when x is already channels-last in memory)."""
     return x.permute(0, 2, 3, 1).contiguous()
@@ -159,11 +176,14 @@ def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=No
 # ---------------------------------------------------------------------------------------------------
 P3_ENABLED = True
 P3_MIN_PIXELS = 16384  # smaller feature maps are launch / latency bound: the in-wave split costs nothing there
+P3_MIN_WORK = 1152     # taps * output channels per activation element below which a split pass costs more than it returns
 
 
 def p3_wanted(pixels: int, cred: int, cout: int, taps: int) -> bool:
     """is the piece-image path worth one split pass over the activation operand?  (reduction channels cred, output channels cout)"""
-    return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= 64 and pixels >= P3_MIN_PIXELS and taps * cout >= 576
+    # one split pass moves 10 B per element (2.3 ps at 4.4 TB/s); the convolution spends 2 * taps * cout FLOP per element (3 x 3, 64 outputs:
+    # 7.7 ps at 150 TFLOP/s) and gains ~20 % from the pieces: worth it from taps * cout = 1152 up (3 x 3 with 128 outputs)
+    return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= 64 and pixels >= P3_MIN_PIXELS and taps * cout >= P3_MIN_WORK
 
 
 def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: float = 0.0) -> Optional[torch.Tensor]:
@@ -398,7 +418,19 @@ class _Conv2d(torch.autograd.Function):
             d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
             gwf = _zeros_like(wf)
             want_gb = ctx.has[0] and ctx.needs_input_grad[2]
-            fuse = want_gb and (kh * kw * c) % 4 == 0
+            # both operands as piece images (x's from the forward, dy's shared with the adjoint above): the weight gradient runs without
+            # split arithmetic; the bias gradient then takes its own pass
+            if ctx.x3 is not None and pad_mode == 0 and c % 32 == 0 and k % 16 == 0 and p3_wanted(gy.numel() // k, c, k, kh * kw):
+                gy3 = p3_of(gy)
+                if gy3 is not None:
+                    d.w3 = None
+                    d.x3, d.y3 = ctx.x3.data_ptr(), gy3.data_ptr()
+                    want_gb_fused = False
+                else:
+                    want_gb_fused = want_gb
+            else:
+                want_gb_fused = want_gb
+            fuse = want_gb_fused and (kh * kw * c) % 4 == 0
             if fuse:
                 gb = _zeros(k, x.device, torch.float32)
             with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
@@ -686,6 +718,10 @@ class _ConvTranspose2d(torch.autograd.Function):
                 lib.conv2d_fwd_f32(C.byref(d0), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
             gwf = _zeros_like(wf)
+            if ctx.x3 is not None and cb % 32 == 0 and cs % 16 == 0:  # the big image's pieces (shared with the adjoint above) and x's from the forward
+                gy3 = p3_of(gy)
+                if gy3 is not None:
+                    d.x3, d.y3 = gy3.data_ptr(), ctx.x3.data_ptr()
             with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:

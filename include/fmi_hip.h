@@ -40,6 +40,13 @@ typedef enum {
 
 const char* fmi_status_string(int status);
 int fmi_version(void);
+/* Reproducible mode (also FMI_DETERMINISTIC=1 in the environment at load time).  Default off: split reductions meet through fp32 atomics,
+ * whose arrival order changes the rounding from run to run.  On: every entry picks a decomposition with ONE contributing workgroup per
+ * accumulated address (no split reductions, one-block reduction tails, gather-form adjoints), and fmi_attention_bwd_det_f32 replaces the
+ * atomic dQ by per-key-block partial tiles added in a fixed order: two runs are bit-identical.  Slower; a checking mode.
+ * fmi_set_deterministic returns the previous setting. */
+int fmi_set_deterministic(int on);
+int fmi_get_deterministic(void);
 
 /* ------------------------------------------------------------------------
  * Dense batched GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
@@ -131,6 +138,8 @@ int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* dy, const f
 int fmi_conv2d_dgrad_masked_add_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope,
                                     const float* gadd, float* dx, void* stream);
 /* dwf[tap][C][K] += sum over pixels x (gathered) * dy ; fp32 atomics, caller zeroes dwf.
+ * With d->x3 (piece image of x) AND d->y3 (here an INPUT: the piece image of dy) given, dbias == NULL, C % 32 == 0, K % 16 == 0 and dense
+ * tensors, the product runs on the pieces (csrc/conv_p3.h: transposed LDS reads, no split arithmetic); results agree to fp32 rounding.
  * dbias (may be NULL; needs kh*kw*C % 4 == 0 and batch_w == 1): dbias[k] += sum over pixels dy[p][k], computed by the same
  * GEMM as one extra row of ones -- no separate pass over dy; caller zeroes it. */
 int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, const float* dy, float* dwf, float* dbias,

@@ -152,6 +152,7 @@ def test_autograd_path_takes_the_pieces(dev, FF, monkeypatch):
     for on in (False, True):
         monkeypatch.setattr(FF, "P3_ENABLED", on)
         monkeypatch.setattr(FF, "P3_MIN_PIXELS", 0)
+        monkeypatch.setattr(FF, "P3_MIN_WORK", 0)
         for t in (w1, w2, x):
             t.grad = None
         pw1, pw2 = FF.prepare_weights([(w1, None, None), (w2, None, None)])
@@ -163,3 +164,36 @@ def test_autograd_path_takes_the_pieces(dev, FF, monkeypatch):
         torch.testing.assert_close(a, b, rtol=0, atol=2e-6 * float(b.abs().max()))
     for a, b in zip(res[True][2:], res[False][2:]):
         torch.testing.assert_close(a, b, rtol=0, atol=1e-5 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", [(2, 64, 64, 40, 36, 3, 1, 1), (1, 128, 192, 33, 31, 3, 1, 1), (2, 64, 128, 24, 24, 1, 1, 0),
+                                                      (2, 64, 64, 32, 32, 3, 2, 1), (1, 32, 64, 20, 20, 3, 1, 1), (1, 64, 32, 64, 64, 3, 1, 1),
+                                                      (8, 128, 128, 64, 64, 3, 1, 1), (1, 96, 48, 17, 19, 3, 1, 1)])
+def test_weight_gradient_with_pieces_of_both_operands(dev, FF, n, c, k, h, w, ksz, stride, pad):
+    """fmi_conv2d_wgrad_f32 given the piece images of x (d.x3) and of dy (d.y3) against the same entry without them (2e-6 of the largest
+    entry: same exact products, another summation order across pixel splits) and against torch fp32 autograd on the CPU (1e-5)"""
+    lib = _lib()
+    st = FF._st()
+    g = torch.Generator().manual_seed(c + 5 * k + h)
+    x = torch.randn(n, h, w, c, generator=g)
+    wt_ = torch.randn(k, c, ksz, ksz, generator=g) / (c * ksz * ksz) ** 0.5
+    xd = x.to(dev)
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad)
+    gy = torch.randn(n, oh, ow, k, generator=g)
+    gyd = gy.to(dev)
+    x3, _ = _split(FF, xd)
+    gy3, _ = _split(FF, gyd)
+    outs = []
+    for use in (False, True):
+        d, _, _ = FF.conv_desc(n, h, w, c, k, ksz, ksz, stride, pad)
+        if use:
+            d.x3, d.y3 = x3.data_ptr(), gy3.data_ptr()
+        dw = torch.zeros(ksz * ksz, c, k, device=dev)
+        lib.conv2d_wgrad_f32(C.byref(d), FF._p(xd), FF._p(gyd), FF._p(dw), None, 1, 0, st)
+        outs.append(dw)
+    scale = float(outs[0].abs().max())
+    torch.testing.assert_close(outs[1], outs[0], rtol=0, atol=2e-6 * scale)
+    wr = wt_.clone().requires_grad_(True)
+    F.conv2d(x.permute(0, 3, 1, 2), wr, None, stride=stride, padding=pad).backward(gy.permute(0, 3, 1, 2))
+    ref = wr.grad.permute(2, 3, 1, 0).reshape(ksz * ksz, c, k)
+    torch.testing.assert_close(outs[1].cpu(), ref, rtol=1e-5, atol=1e-5 * scale)
