@@ -192,7 +192,14 @@ def test_c2_model_full_size_against_oracle(dev):
     """BASELINE configs[1] at its REAL size -- 256 x 256 input, full channel widths (encoder ngf 32 / img_f 128 / L 6, decoder
     ngf 32 / img_f 256 incl. the 16 384-token Auto_Attn and the 1024^2 Output block, ResDis discriminator, full-width VGG16[:23]),
     batch 1 (the path has no batch-coupled op): generated image, the five losses of GANOptimizer.__call__ and the SpectralNorm state
-    after the step against the CPU oracle on the same weights, inputs and N(0,1) draws -- 1e-3 relative (north_star)."""
+    after the step against the CPU oracle on the same weights, inputs and N(0,1) draws -- 1e-3 relative (north_star).
+
+    The HIP side runs twice from the same state: in the default mode (split reductions meet through fp32 atomics) and in the library's
+    reproducible mode (FF.deterministic(): one contributor per accumulated address).  Both must meet 1e-3 on the image and on four of the
+    five losses.  The contextual term normalises cosine distances by (row minimum + 1e-5) (external_function.py:262); the masked-out
+    pixels of both images are identical, so that minimum is ~0 and an absolute 1e-7 in a distance is 1e-2 in the exponent: its bound is
+    CX_TOL_REPRODUCIBLE in the reproducible mode -- where the value is a fixed function of the inputs -- and 5e-3 in the default mode,
+    whose own run-to-run spread on this term is ~1e-3."""
     from face_mask_inpaint_amd import functional as FF
     from face_mask_inpaint_amd.modules.loss import GANOptimizer
     from face_mask_inpaint_amd.modules.model import ReferenceFill
@@ -200,40 +207,49 @@ def test_c2_model_full_size_against_oracle(dev):
     from face_mask_inpaint_amd.optim import FusedAdam
     from oracle import picnet_cpu as O  # checker
 
+    CX_TOL_REPRODUCIBLE = 1e-3
     enc = dict(type="pluralistic", ngf=32, z_nc=128, img_f=128, layers=5, norm="none", activation="LeakyReLU", L=6)
     dec = dict(ngf=32, z_nc=256, img_f=256, layers=5, norm="instance", activation="LeakyReLU", L=0)
-    torch.manual_seed(2)
-    G = ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(256, 256))
-    D = network.define_d(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
-    with torch.no_grad():
-        G.decoder.attn1.gamma.fill_(0.4)  # gamma is 0 at initialisation: make the 16 384-token attention visible in the image
-        D.attn2.gamma.fill_(-0.3)
-    optG, optD = FusedAdam(G.parameters(), lr=1e-5), FusedAdam(D.parameters(), lr=1e-5)
-    gopt = GANOptimizer(optD, optG)
+
+    def build():
+        torch.manual_seed(2)
+        G = ReferenceFill(None, dict(enc), dict(dec), use_att=True, out_size=(256, 256))
+        D = network.define_d(ndf=32, img_f=128, layers=5, norm="none", activation="LeakyReLU", model_type="ResDis")
+        with torch.no_grad():
+            G.decoder.attn1.gamma.fill_(0.4)  # gamma is 0 at initialisation: make the 16 384-token attention visible in the image
+            D.attn2.gamma.fill_(-0.3)
+        optG, optD = FusedAdam(G.parameters(), lr=1e-5), FusedAdam(D.parameters(), lr=1e-5)
+        return G, D, GANOptimizer(optD, optG)
+
+    G, D, gopt = build()
     PG, PD = O.prepare_params(G.state_dict()), O.prepare_params(D.state_dict())
     PV = O.prepare_params(gopt.vgg_loss.state_dict(), frozen=True)
+    vgg_sd = {k: v.clone() for k, v in gopt.vgg_loss.state_dict().items()}
     src, ref, gt, mask, eps_p, eps_q = O.synthetic_batch(1, 256, seed=77, feat_hw=32, z_nc=128)
-    G, D, gopt = G.to(dev), D.to(dev), gopt.to(dev)
-    m = FF.binarise_mask(mask.to(dev))
-    assert torch.equal(m.cpu(), O.binarise_mask(mask))
-    gen = G(src.to(dev), ref.to(dev), src_mask=m, eps=(eps_p.to(dev), eps_q.to(dev)))
-    got = [float(v) for v in gopt(D, src.to(dev), gt.to(dev), ref.to(dev), gen, m)]
     torch.set_num_threads(min(16, torch.get_num_threads()))
     og = torch.optim.Adam(O.unique_trainable(PG), lr=1e-5)
     od = torch.optim.Adam(O.unique_trainable(PD), lr=1e-5)
     want = O.train_step(PG, PD, PV, og, od, src, gt, ref, mask, eps_p, eps_q, out_size=(256, 256))
     ogen = want[0]
-    assert gen.shape == ogen.shape == (1, 3, 256, 256)
-    err = float((gen.detach().cpu() - ogen).abs().max())
-    assert err <= 1e-3 * float(ogen.abs().max()), f"image: {err:.3e}"
-    for name, a, b in zip(("d_loss", "g_loss", "perceptual", "style", "contextual"), got, want[1:]):
-        # the contextual term normalises cosine distances by (row minimum + 1e-5) (external_function.py:262): the masked-out pixels of
-        # both images are identical, so the minimum is ~0 and an absolute 1e-7 in a distance is 1e-2 in the exponent -- run to run the
-        # HIP value itself moves by ~1e-3 relative (fp32 atomics in split reductions)
-        tol = 5e-3 if name == "contextual" else 1e-3
-        assert abs(a - float(b)) <= tol * abs(float(b)) + 1e-12, f"{name}: {a:.6e} vs {float(b):.6e}"
-    sd = {**{"G." + k: v for k, v in G.state_dict().items()}, **{"D." + k: v for k, v in D.state_dict().items()}}
-    for k in ("G.decoder.decoder4.conv2.module.weight_u", "G.src_encoder.prior.conv1.module.weight_v", "D.block0.conv1.module.weight_u", "D.block5.conv2.module.weight_v"):
-        P = PG if k.startswith("G.") else PD
-        if k[2:] in P:
-            torch.testing.assert_close(sd[k].cpu(), P[k[2:]], rtol=1e-4, atol=1e-6, msg=lambda mm, k=k: f"{k}: {mm}")
+    for reproducible in (False, True):
+        G, D, gopt = build()
+        gopt.vgg_loss.load_state_dict(vgg_sd)
+        G, D, gopt = G.to(dev), D.to(dev), gopt.to(dev)
+        with FF.deterministic(reproducible):
+            m = FF.binarise_mask(mask.to(dev))
+            assert torch.equal(m.cpu(), O.binarise_mask(mask))
+            gen = G(src.to(dev), ref.to(dev), src_mask=m, eps=(eps_p.to(dev), eps_q.to(dev)))
+            got = [float(v) for v in gopt(D, src.to(dev), gt.to(dev), ref.to(dev), gen, m)]
+        mode = "reproducible" if reproducible else "default"
+        print("full-size C2 losses, %s mode: %s   oracle: %s" % (mode, ["%.8e" % v for v in got], ["%.8e" % float(v) for v in want[1:]]))
+        assert gen.shape == ogen.shape == (1, 3, 256, 256)
+        err = float((gen.detach().cpu() - ogen).abs().max())
+        assert err <= 1e-3 * float(ogen.abs().max()), f"image ({mode}): {err:.3e}"
+        for name, a, b in zip(("d_loss", "g_loss", "perceptual", "style", "contextual"), got, want[1:]):
+            tol = 1e-3 if name != "contextual" else (CX_TOL_REPRODUCIBLE if reproducible else 5e-3)
+            assert abs(a - float(b)) <= tol * abs(float(b)) + 1e-12, f"{name} ({mode}): {a:.6e} vs {float(b):.6e}"
+        sd = {**{"G." + k: v for k, v in G.state_dict().items()}, **{"D." + k: v for k, v in D.state_dict().items()}}
+        for k in ("G.decoder.decoder4.conv2.module.weight_u", "G.src_encoder.prior.conv1.module.weight_v", "D.block0.conv1.module.weight_u", "D.block5.conv2.module.weight_v"):
+            P = PG if k.startswith("G.") else PD
+            if k[2:] in P:
+                torch.testing.assert_close(sd[k].cpu(), P[k[2:]], rtol=1e-4, atol=1e-6, msg=lambda mm, k=k: f"{k}: {mm}")
