@@ -25,11 +25,18 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 
 #else  // ------------------------------- device build -------------------------------
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #define FMI_WAVE 64
 
 extern "C" int fmi_deterministic_flag;  // misc.hip: reproducible mode (single-contributor reductions), see fmi_set_deterministic
 static inline bool fmi_det() { return fmi_deterministic_flag != 0; }
+// FMI_BLOCKED_ACC=1: blocked accumulation (a second accumulator set, flushed every 512 reduction elements) also in the default mode for
+// the kernels where it costs an occupancy step; the reproducible mode always takes it, the eight-wave tiles take it for free
+static inline bool fmi_blocked_acc() {
+  static const bool v = getenv("FMI_BLOCKED_ACC") != nullptr && getenv("FMI_BLOCKED_ACC")[0] != '0';
+  return v;
+}
 
 static inline int fmi_launch_status() {
   hipError_t e = hipGetLastError();

@@ -430,6 +430,28 @@ extern "C" int fmi_conv2d_wgrad_f32(const fmi_conv_desc* d, const float* x, cons
 // vector form (K % 4 == 0, K/4 divides 256): the tensor is streamed as float4, 256 threads cover 256/(K/4) rows per
 // pass with fully coalesced 16-byte loads; threads owning the same 4 channels are combined through LDS.
 // ---------------------------------------------------------------------------------------------
+// reproducible mode runs ONE workgroup over all rows: its threads then add tens of thousands of terms each, so they carry fp64 sums (the
+// default mode's many short fp32 chains are more accurate than one long one: measured on the whole-pSp fixture)
+__global__ void __launch_bounds__(256) bias_grad_vec_f64_kernel(const float* __restrict__ g, int64_t rows, int K4, float* __restrict__ dbias) {
+  __shared__ double part[256][4];
+  const int cg = threadIdx.x % K4, rl = threadIdx.x / K4, RL = 256 / K4;
+  double s[4] = {0, 0, 0, 0};
+  for (int64_t r = rl; r < rows; r += RL) {
+    const float4 v = reinterpret_cast<const float4*>(g)[r * K4 + cg];
+    s[0] += v.x, s[1] += v.y, s[2] += v.z, s[3] += v.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[threadIdx.x][e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < K4) {
+    double t[4] = {0, 0, 0, 0};
+    for (int l = 0; l < RL; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += part[l * K4 + threadIdx.x][e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dbias + 4 * threadIdx.x + e, (float)t[e]);
+  }
+}
 __global__ void __launch_bounds__(256) bias_grad_vec_kernel(const float* __restrict__ g, int64_t rows, int K4,
                                                             float* __restrict__ dbias, int64_t rows_per_block) {
   __shared__ float4 part[256];
@@ -496,7 +518,9 @@ extern "C" int fmi_bias_grad_f32(const float* g, int64_t rows, int K, int cstrid
   const int64_t rpb = ceil_div64(rows, blocks);
   blocks = ceil_div64(rows, rpb);
   const int K4 = K / 4;
-  if (K % 4 == 0 && cstride == K && K4 <= 256 && (K4 & (K4 - 1)) == 0 && (((uintptr_t)g) & 15) == 0)
+  if (fmi_det() && K % 4 == 0 && cstride == K && K4 <= 256 && (K4 & (K4 - 1)) == 0 && (((uintptr_t)g) & 15) == 0)
+    hipLaunchKernelGGL(bias_grad_vec_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, rows, K4, dbias);
+  else if (K % 4 == 0 && cstride == K && K4 <= 256 && (K4 & (K4 - 1)) == 0 && (((uintptr_t)g) & 15) == 0)
     hipLaunchKernelGGL(bias_grad_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K4, dbias, rpb);
   else
     hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, rows, K, cstride, dbias, rpb);

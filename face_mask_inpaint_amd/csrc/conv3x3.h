@@ -23,7 +23,8 @@ struct C3Args {
 
 // W3: the weight tiles arrive as bf16 piece images ([3 kx][3 pieces][2 channel groups][BN] 16-byte chunks per stage) and are read as
 // ready B fragments; only the activation fragments are split in registers.
-template <class T, bool W3>
+// FL: blocked accumulation (a second accumulator set, flushed every 10 steps = 480 reduction elements), see conv_p3.h
+template <class T, bool W3, bool FL = false>
 __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
   constexpr int BM = T::BM, BN = T::BN, BK = 16;
   constexpr int RA = ((BM + 2 + 15) / 16) * 16;  // rows of the A image (multiple of the 16 rows one wave instruction writes)
@@ -193,7 +194,16 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
   };
 
   if (it_begin < it_end) issue(it_begin, 0);
-  int st = 0;
+  int st = 0, since = 0;
+  f32x16 acc2[FL ? T::TM : 1][FL ? T::TN : 1];
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  }
   for (int it = it_begin; it < it_end; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of step `it` have landed
     __builtin_amdgcn_s_barrier();
@@ -201,6 +211,26 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
     if (it + 1 < it_end) issue(it + 1, st ^ 1);
     compute(st);
     st ^= 1;
+    if constexpr (FL) {
+      if (++since == 10 || it + 1 == it_end) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              acc2[i][j][r] += acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+        since = 0;
+      }
+    }
+  }
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = acc2[i][j];
   }
   store_tile<ConvEp, T>(ep, acc, M, a.Nout, m0 + wm, n0 + wn, lh, l31);
 }
@@ -222,12 +252,17 @@ static int launch_conv3x3(const C3Args& a, const ConvEp& ep, int M, int ksplit, 
 #define C3_LAUNCH_(TILE, W3)                                                                                                  \
   do {                                                                                                                        \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(a.Nout, TILE::BN);                                            \
-    hipLaunchKernelGGL((conv3x3_dma_kernel<TILE, W3>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, a, ep, M, (int)tn, ksplit, \
-                       it_chunk);                                                                                             \
+    if (fl)                                                                                                                   \
+      hipLaunchKernelGGL((conv3x3_dma_kernel<TILE, W3, true>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, a, ep, M, (int)tn, \
+                         ksplit, it_chunk);                                                                                   \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((conv3x3_dma_kernel<TILE, W3>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, a, ep, M, (int)tn, ksplit, \
+                         it_chunk);                                                                                           \
   } while (0)
 #define C3_LAUNCH(TILE) C3_LAUNCH_(TILE, false)
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(a.Nout, bn) * ksplit; };
   const int N = a.Nout;
+  const bool fl = it_chunk > 13 && (fmi_det() || fmi_blocked_acc());  // blocked accumulation of a long unsplit reduction (conv_p3.h)
 #if FMI_X6
   static const bool w3_off = getenv("FMI_W3_OFF") != nullptr;  // debug A/B: split the weight fragments in registers as well
   // piece images of the weights: 2 x 27 KB of LDS at 64 columns (two workgroups per CU; a 128-column piece tile would leave one).  Measured

@@ -86,10 +86,36 @@ __device__ __forceinline__ void glds16_p3(const void* g, uint32_t dst) {
                : "memory");
 }
 
+template <class T>
+__device__ __forceinline__ void p3_acc_clear(f32x16 (&a)[T::TM][T::TN]) {
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[i][j][r] = 0.f;
+}
+// dst += src; src = 0
+template <class T>
+__device__ __forceinline__ void p3_acc_flush(f32x16 (&src)[T::TM][T::TN], f32x16 (&dst)[T::TM][T::TN]) {
+#pragma unroll
+  for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dst[i][j][r] += src[i][j][r];
+        src[i][j][r] = 0.f;
+      }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // generic implicit GEMM: rows = anchors (output pixels / adjoint phase pixels), k = (tap, channel), columns = output channels
 // ---------------------------------------------------------------------------------------------------------------------------
-template <class T>
+// FL: blocked accumulation -- every 512 reduction elements the accumulators are added into a second set and cleared, so that a long
+// reduction is a sum of short fp32 chains (what a CPU library's blocked kernels do) instead of ONE chain of up to 4 608 products:
+// measured on the whole-pSp fixture, the unsplit sequential form is 3 x further from float64 than the reference's own fp32 run.
+template <class T, bool FL = false>
 __global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, ConvEp ep, int M, int N, int K, int tiles_n, int ksplit, int kchunk) {
   constexpr int BM = T::BM, BN = T::BN, BK = 16;
   constexpr int NIA = BM * 6 / 64, NIB = BN * 6 / 64;  // wave instructions (1 KiB each) of the A / B image of a stage
@@ -192,6 +218,8 @@ __global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, Con
   const int nt = (k_end - k_begin + BK - 1) / BK;
   if (nt > 0) issue(k_begin, 0);
   int st = 0;
+  f32x16 acc2[FL ? T::TM : 1][FL ? T::TN : 1];
+  if constexpr (FL) p3_acc_clear<T>(acc2);
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's copies of tile t have landed
 #if !(FMI_P3_EXP & 16)
@@ -201,7 +229,10 @@ __global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, Con
     if (t + 1 < nt) issue(k_begin + (t + 1) * BK, st ^ 1);
     compute(st);
     st ^= 1;
+    if constexpr (FL)
+      if ((t & 31) == 31) p3_acc_flush<T>(acc, acc2);
   }
+  if constexpr (FL) p3_acc_flush<T>(acc2, acc);  // acc = acc + acc2 (the tail block joins the flushed ones)
   store_tile<ConvEp, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);
 }
 
@@ -219,10 +250,17 @@ static int launch_gemm_p3(const ConvK3& la, const ConvWX3& lb, const ConvEp& ep,
   do {                                                                                                                                         \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                                                  \
     if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                                                    \
-    hipLaunchKernelGGL((gemm_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn, ksplit, \
-                       kchunk);                                                                                                                \
+    if (fl)                                                                                                                                    \
+      hipLaunchKernelGGL((gemm_p3_kernel<TILE, true>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn, ksplit, \
+                         kchunk);                                                                                                              \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((gemm_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(256), 0, st, la, lb, ep, M, N, K, (int)tn, ksplit, \
+                         kchunk);                                                                                                              \
   } while (0)
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(N, bn) * ksplit; };
+  // blocked accumulation (a second accumulator set: ~64 registers, an occupancy step for the 128 x 128 tile) where one workgroup adds more
+  // than ~600 products in a row AND the run asks for it: the reproducible mode, where no split reduction blocks the sum for us
+  const bool fl = kchunk > 640 && (fmi_det() || fmi_blocked_acc());
   static const int tile_dbg = getenv("FMI_P3_TILE") ? atoi(getenv("FMI_P3_TILE")) : 0;  // experiment: force a tile
   if (tile_dbg == 1) { P3_LAUNCH(Tile128x128); return fmi_launch_status(); }
   if (tile_dbg == 2) { P3_LAUNCH(Tile64x128); return fmi_launch_status(); }
@@ -266,7 +304,7 @@ struct C3P3Args {
   FastDiv dW, dHW;
 };
 
-template <class T>
+template <class T, bool FL = false>
 __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
   constexpr int BM = T::BM, BN = T::BN, NW = T::NW;
   constexpr int NIA = ((BM + 2) * 6 + 63) / 64;  // wave instructions (1 KiB) of the A image
@@ -391,7 +429,9 @@ __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, Conv
   };
 
   if (it_begin < it_end) issue(it_begin, 0);
-  int st = 0;
+  int st = 0, since = 0;
+  f32x16 acc2[FL ? T::TM : 1][FL ? T::TN : 1];
+  if constexpr (FL) p3_acc_clear<T>(acc2);
   for (int it = it_begin; it < it_end; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -399,7 +439,14 @@ __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, Conv
     if (it + 1 < it_end) issue(it + 1, st ^ 1);
     compute(st);
     st ^= 1;
+    if constexpr (FL) {  // a step adds 48 products per output (three taps x 16 channels): a block of 10 steps = 480
+      if (++since == 10) {
+        p3_acc_flush<T>(acc, acc2);
+        since = 0;
+      }
+    }
   }
+  if constexpr (FL) p3_acc_flush<T>(acc2, acc);
   store_tile<ConvEp, T>(ep, acc, M, a.Nout, m0 + wm, n0 + wn, lh, l31);
 }
 
@@ -420,16 +467,24 @@ static int launch_conv3x3_p3(const C3P3Args& a, const ConvEp& ep, int M, int ksp
 #define C3P3_LAUNCH(TILE)                                                                                                                          \
   do {                                                                                                                                             \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(a.Nout, TILE::BN);                                                                 \
-    hipLaunchKernelGGL((conv3x3_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(TILE::NW * 64), 0, st, a, ep, M, (int)tn, ksplit, \
-                       it_chunk);                                                                                                                  \
+    if (fl)                                                                                                                                        \
+      hipLaunchKernelGGL((conv3x3_p3_kernel<TILE, true>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(TILE::NW * 64), 0, st, a, ep, M, (int)tn, \
+                         ksplit, it_chunk);                                                                                                        \
+    else                                                                                                                                           \
+      hipLaunchKernelGGL((conv3x3_p3_kernel<TILE>), dim3((unsigned)(tm * tn), (unsigned)ksplit), dim3(TILE::NW * 64), 0, st, a, ep, M, (int)tn,    \
+                         ksplit, it_chunk);                                                                                                        \
   } while (0)
   auto wgs = [&](int bm, int bn) { return ceil_div64(M, bm) * ceil_div64(a.Nout, bn) * ksplit; };
   static const int tile_dbg = getenv("FMI_C3P3_TILE") ? atoi(getenv("FMI_C3P3_TILE")) : 0;  // experiment: force a tile
   const int N = a.Nout;
+  // blocked accumulation: the eight-wave tiles hold one workgroup per CU (LDS) at 150 of 256 registers -- the second accumulator set is
+  // free there, so every long reduction takes it; the four-wave tiles only on request (occupancy)
+  const bool long_red = it_chunk > 13;
   int pick;
   if (tile_dbg) pick = tile_dbg;
   else if (N > 64) pick = wgs(256, 128) >= 256 ? 1 : 3;
   else pick = wgs(256, 64) >= 256 ? 2 : 4;
+  const bool fl = long_red && (pick <= 2 || fmi_det() || fmi_blocked_acc());
   if (pick == 1) C3P3_LAUNCH(C3P3_256x128);
   else if (pick == 2) C3P3_LAUNCH(C3P3_256x64);
   else if (pick == 3) C3P3_LAUNCH(C3P3_128x128);
@@ -458,7 +513,7 @@ struct WgP3Args {
   int tiles, ksplit, xcd_splits;
 };
 
-template <class T>
+template <class T, bool FL = false>
 __global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int tiles_n) {
   constexpr int BM = T::BM, BN = T::BN, BK = 16, NW = T::NW;
   constexpr int GA = BM / 32, GB = BN / 32;       // 32-row groups per operand tile
@@ -582,6 +637,8 @@ __global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int ti
   const int nt = (k_end - k_begin + BK - 1) / BK;
   if (nt > 0) issue(k_begin, 0);
   int st = 0;
+  f32x16 acc2[FL ? T::TM : 1][FL ? T::TN : 1];
+  if constexpr (FL) p3_acc_clear<T>(acc2);
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -589,7 +646,10 @@ __global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int ti
     if (t + 1 < nt) issue(k_begin + (t + 1) * BK, st ^ 1);
     compute(st);
     st ^= 1;
+    if constexpr (FL)
+      if ((t & 31) == 31) p3_acc_flush<T>(acc, acc2);
   }
+  if constexpr (FL) p3_acc_flush<T>(acc2, acc);
 #pragma unroll
   for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
@@ -642,10 +702,17 @@ static int launch_wgrad_p3(const fmi_conv_desc* d, const uint16_t* x3, const uin
   const int64_t nwg = a.xcd_splits ? tm * tn * ceil_div64(ksplit, 8) * 8 : tm * tn;
   if (nwg > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)nwg, a.xcd_splits ? 1u : (unsigned)ksplit);
-  if (big) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_256x128>), grid, dim3(512), 0, st, a, (int)tn);
-  else if (bn == 32) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x32>), grid, dim3(256), 0, st, a, (int)tn);
-  else if (bn == 64) hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x64>), grid, dim3(256), 0, st, a, (int)tn);
-  else hipLaunchKernelGGL((wgrad_p3_kernel<WG3_128x128>), grid, dim3(256), 0, st, a, (int)tn);
+  const bool fl = a.kchunk > 640 && (fmi_det() || fmi_blocked_acc());  // blocked accumulation of a long unsplit pixel reduction
+#define WG3_LAUNCH(TILE, NT)                                                                              \
+  do {                                                                                                    \
+    if (fl) hipLaunchKernelGGL((wgrad_p3_kernel<TILE, true>), grid, dim3(NT), 0, st, a, (int)tn);         \
+    else hipLaunchKernelGGL((wgrad_p3_kernel<TILE>), grid, dim3(NT), 0, st, a, (int)tn);                  \
+  } while (0)
+  if (big) WG3_LAUNCH(WG3_256x128, 512);
+  else if (bn == 32) WG3_LAUNCH(WG3_128x32, 256);
+  else if (bn == 64) WG3_LAUNCH(WG3_128x64, 256);
+  else WG3_LAUNCH(WG3_128x128, 256);
+#undef WG3_LAUNCH
   return fmi_launch_status();
 }
 static bool wgrad_p3_ok(const fmi_conv_desc* d, const void* x3, const void* dy3) {

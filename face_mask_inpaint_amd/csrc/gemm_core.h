@@ -861,7 +861,9 @@ struct is_split3 : std::false_type {};
 template <class L>
 struct is_split3<L, std::void_t<decltype(L::SPLIT3)>> : std::integral_constant<bool, L::SPLIT3> {};
 
-template <class LA, class LB, class EP, class T>
+// FL: blocked accumulation -- a second accumulator set, flushed every 32 tiles (512 reduction elements), so that a long unsplit
+// reduction is a sum of short fp32 chains (conv_p3.h)
+template <class LA, class LB, class EP, class T, bool FL = false>
 __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
                                                            int ksplit, int kchunk) {
   #ifndef FMI_NST
@@ -1061,6 +1063,15 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
   for (int p = 0; p < DEPTH; ++p)
     if (p < nt) issue(k_begin + p * BK, p);
   int st = 0, stn = DEPTH;  // stage of tile t, stage tile t+DEPTH goes to
+  f32x16 acc2[FL ? T::TM : 1][FL ? T::TN : 1];
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  }
   for (int t = 0; t < nt; ++t) {
     // tile t must have landed; the newer tiles already issued (at most DEPTH-1 of them) may stay in flight
     int pend = nt - 1 - t;
@@ -1078,6 +1089,25 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
 #endif
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
+    if constexpr (FL) {
+      if ((t & 31) == 31 || t + 1 == nt) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              acc2[i][j][r] += acc[i][j][r];
+              acc[i][j][r] = 0.f;
+            }
+      }
+    }
+  }
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < T::TN; ++j) acc[i][j] = acc2[i][j];
   }
 
   store_tile<EP, T>(ep, acc, M, N, m0 + wm, n0 + wn, lh, l31);
@@ -1108,11 +1138,17 @@ static int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int N, i
     if (i >= a && i < b) dma = false;
     if (getenv("FMI_DMA_TRACE")) fprintf(stderr, "[fmi launch %ld] family %d M %d N %d K %d batch %d ksplit %d dma %d (eligible %d %d)\n", i, family, M, N, K, batch, ksplit, (int)dma, (int)la.dma_ok(), (int)lb.dma_ok());
   }
+  const bool fl = kchunk > 640 && (fmi_det() || fmi_blocked_acc());  // blocked accumulation of a long unsplit reduction (LDS-DMA kernel)
 #define FMI_LAUNCH(TILE)                                                                                      \
   do {                                                                                                        \
     const int64_t tm = ceil_div64(M, TILE::BM), tn = ceil_div64(N, TILE::BN);                                 \
     if (tm * tn > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;                                                   \
     {                                                                                                         \
+      if (dma && fl) {                                                                                        \
+        hipLaunchKernelGGL((gemm_dma_f32_kernel<LA, LB, EP, TILE, true>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
+                           0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                              \
+        break;                                                                                                \
+      }                                                                                                       \
       if (dma) {                                                                                              \
         hipLaunchKernelGGL((gemm_dma_f32_kernel<LA, LB, EP, TILE>), dim3((unsigned)(tm * tn), (unsigned)gy), dim3(256), \
                            0, st, la, lb, ep, M, N, K, (int)tn, ksplit, kchunk);                              \

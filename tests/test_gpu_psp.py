@@ -116,8 +116,15 @@ def test_psp_loss_against_reference_golden(dev, golden):
     assert hasattr(pSpLoss(types.SimpleNamespace(**{**fx["args"], "lpips_lambda": 0.8})), "lpips_loss") and not hasattr(crit, "lpips_loss")
 
 
-def test_psp_whole_train_against_reference(dev, golden):
-    """the WHOLE pSp at full widths (IR-SE50 GradualStyleEncoder with attention on src + ref, latent_avg, 256^2 StyleGAN2 decoder:
+@pytest.mark.parametrize("reproducible", [False, True])
+def test_psp_whole_train_against_reference(dev, golden, reproducible):
+    """reproducible = the library's deterministic mode: the gradients are then a FIXED function of the inputs (two runs are bit-identical,
+    tools/bench_tools/psp_det_probe.py), so the bounds below that absorb run-to-run spread in the default mode are replaced by the
+    measured values with a small margin: parameter-gradient error against float64 median 5.2e-4 / p90 1.7e-3 / worst 5.3e-2 (the
+    reference's own fp32 run: 2.2e-4 / 9.7e-4 / 2.1e-2 -- training-mode BatchNorm at batch 2 is chaotic at this level, the default mode
+    lands between 1.6e-4 and 4.5e-4 from run to run), eval mode median 6.1e-5 / p90 1.7e-4, scalar noise weights 4.8e-2.
+
+    the WHOLE pSp at full widths (IR-SE50 GradualStyleEncoder with attention on src + ref, latent_avg, 256^2 StyleGAN2 decoder:
     BASELINE configs[2] shapes at batch 2) in TRAINING mode, forward + backward, against the imported reference
     (tests/golden/psp_whole.pt, oracle/gen_golden.py:psp_whole_fixture; parameters from oracle/seeded.py on both sides): image and
     W+ codes at 1e-3, the input gradients and EVERY parameter gradient adjudicated by the reference's float64 run, BatchNorm
@@ -139,6 +146,18 @@ def test_psp_whole_train_against_reference(dev, golden):
     for i, (a, b, c, d) in enumerate(cfg["rects"]):
         mask[i, a:b, c:d] = 1
     mask = mask.to(dev)
+    from face_mask_inpaint_amd import functional as FF
+
+    ctx = FF.deterministic(reproducible)
+    ctx.__enter__()
+    request_cleanup = ctx  # left by the finally below
+    try:
+        _psp_whole_body(net, x, ref, mask, fx, cfg, dev, reproducible, check_adjudicated, check_digest, digest_error, seeded_tensor)
+    finally:
+        request_cleanup.__exit__(None, None, None)
+
+
+def _psp_whole_body(net, x, ref, mask, fx, cfg, dev, reproducible, check_adjudicated, check_digest, digest_error, seeded_tensor):
     img, lat = net(x, ref=ref, src_mask=mask, resize=True, randomize_noise=False, return_latents=True)
     _close(lat, fx["latent"], 1e-3, "W+ codes")
     _close(img, fx["image"], 1e-3, "image")
@@ -150,7 +169,8 @@ def test_psp_whole_train_against_reference(dev, golden):
     # 2.2e-4 / 9.7e-4; the eval-mode comparison below is the strict one -- the IR-SE50 convolutions accumulate up to 4608
     # products sequentially in one fp32 MFMA accumulator where oneDNN adds blocked partial sums, so the forward rounding that feeds
     # the kink flips is ~1.7x the CPU's (the decoder, by contrast, is 30x CLOSER to float64 than the reference: test_gpu_stylegan2_ops)
-    check_adjudicated({n: P[n].grad for n in fx["gparams64"]}, fx["gparams"], fx["gparams64"], what="pSp parameters (HIP)", med_factor=3.5, p90_factor=4.5)
+    check_adjudicated({n: P[n].grad for n in fx["gparams64"]}, fx["gparams"], fx["gparams64"], what="pSp parameters (HIP)",
+                      med_factor=2.6 if reproducible else 3.5, p90_factor=2.0 if reproducible else 4.5)
     assert sorted(n for n, p in P.items() if p.grad is None) == fx["no_grad"]
     sd = net.state_dict()
     for k, v in fx["stats_after"].items():
@@ -178,7 +198,9 @@ def test_psp_whole_train_against_reference(dev, golden):
     assert errs[len(errs) // 2][0] <= 2e-4 and errs[int(0.9 * len(errs))][0] <= 1e-3 and errs[-1][0] <= 2e-2, errs[-4:]
     # the 13 one-element noise-weight gradients are sums of 10^5 .. 10^6 signed terms g * noise that nearly cancel: the reference's
     # own fp32 run is 2e-2 from float64 on them, and the HIP value moves by a few 1e-2 from run to run (fp32 atomics)
-    assert scalars[-1][0] <= 0.2, scalars[-3:]
+    assert scalars[-1][0] <= (0.06 if reproducible else 0.2), scalars[-3:]
+    if reproducible:
+        assert errs[len(errs) // 2][0] <= 8e-5 and errs[int(0.9 * len(errs))][0] <= 2.2e-4 and errs[-1][0] <= 6e-3, errs[-4:]
 
 
 def test_lpips_id_and_full_psp_loss_against_reference(dev, golden):
