@@ -22,6 +22,8 @@ static inline void atomicAdd(float* p, float v) { *p += v; }
 typedef void* hipStream_t;
 static inline int fmi_launch_status() { return FMI_OK; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool fmi_det() { return false; }          // the launch-decomposition switches have no meaning in the emulation
+static inline bool fmi_blocked_acc() { return false; }
 
 #else  // ------------------------------- device build -------------------------------
 #include <hip/hip_runtime.h>
