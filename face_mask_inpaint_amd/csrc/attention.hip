@@ -843,6 +843,19 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_kernel(const float* __restri
 // fp32 and is split per tile (700 VALU instructions of ~2 400).  Two launches -- FULL with tiles 0..3, then a light one (S, P and dV of tiles
 // 4..7 only: no V, no dP, no atomics) -- cost 288 instead of 264 MFMAs per tile pair, but the first then holds 96 accumulator registers and
 // the optimiser keeps the V pieces across query tiles.
+#ifdef FMI_ATT_STAMP  // diagnostic build only (tools/bench_tools/build_flags.sh attstamp -DFMI_ATT_STAMP): cycle stamps of the phases of ONE query tile
+__device__ unsigned long long fmi_att_stamps[16];
+extern "C" int fmi_debug_attn_stamps(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(fmi_att_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? FMI_OK : FMI_ERR_LAUNCH;
+}
+#define ATT_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && i0 == 32 * 100 && wid == 0 && lane == 0 && FULL)          \
+      fmi_att_stamps[i] = __builtin_amdgcn_s_memtime();                                                \
+  } while (0)
+#else
+#define ATT_STAMP(i)
+#endif
 template <int D, int NCT, int DVLO, int DVN, bool FULL>
 __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __restrict__ q, const float* __restrict__ v1,
                                                               const float* __restrict__ v2, const float* __restrict__ g1,
@@ -982,6 +995,18 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
     asm volatile("" : "+v"(u.v));
     return u.v;
   };
+  // the same read with the pin left to the caller (pin3 below): a pin is also the point where the wave WAITS for the data, so a fragment
+  // that is read one step ahead gets pinned only after the MFMAs of the current step have been issued
+  auto tr2_nowait = [&](uint32_t a0, uint32_t a1) {
+    union {
+      s16x4_t h[2];
+      bf16x8_t v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)a0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp4)(uintptr_t)a1);
+    return u.v;
+  };
+  auto pin3 = [&](bf16x8_t (&a)[3]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])); };
   // per-lane address parts
   const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3, gb = (lane >> 4) & 1;
   const uint32_t g_row = lds0 + (uint32_t)(l31 * GP);                  // row fragments of gO: + piece, + swizzled chunk
@@ -1006,6 +1031,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
   lstore();
   __syncthreads();
   for (int i0 = 0; i0 < T; i0 += 32) {
+    ATT_STAMP(0);
     // ---- S[q][key], dP[q][key]: lane = key, registers = queries
     f32x16 sp, dp;
 #pragma unroll
@@ -1013,137 +1039,298 @@ __global__ void __launch_bounds__(256, 1) attn_bwd2_x6_kernel(const float* __res
       sp[r] = 0.f;
       dp[r] = 0.f;
     }
+    {  // fragments of step kk + 1 are read before the MFMAs of step kk are issued
+      auto s_frag = [&](int kk, bf16x8_t (&a)[3], bf16x8_t (&b)[3]) {
 #pragma unroll
-    for (int kk = 0; kk < D / 16; ++kk) {
-      bf16x8_t a[3], b[3];
+        for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(q_row + (uint32_t)(pc * QIMG + kk * 32));
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(q_row + (uint32_t)(pc * QIMG + kk * 32));
+        for (int pc = 0; pc < 3; ++pc) b[pc] = *(lp8)(uintptr_t)(k_row + (uint32_t)(pc * KIMG + kk * 32));
+      };
+      bf16x8_t a[3], b[3], an[3], bn[3];
+      s_frag(0, a, b);
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) b[pc] = *(lp8)(uintptr_t)(k_row + (uint32_t)(pc * KIMG + kk * 32));
-      sp = mfma_x6(a, b, sp);
+      for (int kk = 0; kk < D / 16; ++kk) {
+        if (kk + 1 < D / 16) s_frag(kk + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        sp = mfma_x6(a, b, sp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          a[pc] = an[pc];
+          b[pc] = bn[pc];
+        }
+      }
     }
-    if constexpr (FULL) {  // software pipeline of depth one: the fragment of step kk + 1 is read while step kk multiplies
+    ATT_STAMP(1);
+    // The swizzled chunk offsets of the fragment reads are two instructions each.  Computed from the plain lane constants they are
+    // loop-invariant, and the optimiser keeps all of them (one per step: ~48 registers) across the tile loop -- parked in AGPRs and
+    // fetched with v_accvgpr_read at best, spilled to scratch and reloaded in front of the read at worst.  The asm makes the lane
+    // constant opaque at each use, so the offset is recomputed where it is needed.
+    auto gt_frag = [&](int s, int c, bf16x8_t (&a)[3]) {  // gO^T fragment: channels 32 c .., queries 16 s ..
+      int tx = g_tx;
+      asm volatile("" : "+v"(tx));
+      const uint32_t ch0 = (uint32_t)(16 * (((4 * c) & 15) ^ tx) + 16 * ((4 * c) & ~15));
+      const uint32_t ch1 = (uint32_t)(16 * (((4 * c) & 15) ^ tx ^ 2) + 16 * ((4 * c) & ~15));
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        a[pc] = tr2_nowait(g_tr + (uint32_t)(pc * GIMG + 16 * s * GP) + ch0, g_tr + (uint32_t)(pc * GIMG + (16 * s + 8) * GP) + ch1);
+    };
+    if constexpr (FULL) {
+      // ---- P first (it needs S only), then ONE loop over the channel steps that carries both products whose reduction runs over the
+      // channels / whose output is channels: dP[q][key] += gO[q][c] V[key][c] (step kk: 16 channels; the V pieces are split per step,
+      // ~45 VALU instructions) and dV^T[c][key] += gO^T[c][q] P[q][key] (step j = kk: one 32-channel tile of one 16-query half; no VALU).
+      // Alone, the dP steps are bound by the split (an MFMA gap hides about five vector instructions: 309 cycles a step against 192 of
+      // MFMA) while the dV steps leave their gaps empty; together a step has 12 MFMAs for the same 45 instructions.  Every fragment of
+      // step kk + 1 is read / split before the MFMAs of step kk are issued and waited for (pinned) after them.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sp[r] = __expf(sp[r] - lse_i[(r & 3) + 8 * (r >> 2) + 4 * lh]);
+      bf16x8_t pp[2][3];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float f[8] = {sp[8 * s], sp[8 * s + 1], sp[8 * s + 2], sp[8 * s + 3], sp[8 * s + 4], sp[8 * s + 5], sp[8 * s + 6], sp[8 * s + 7]};
+        split3_bf16(f, pp[s]);
+      }
       auto g_frag = [&](int kk, bf16x8_t (&a)[3]) {
-        const uint32_t ad = g_row + (uint32_t)(16 * (((2 * kk) & 15) ^ g_rx) + 16 * ((2 * kk) & ~15));
+        int rx = g_rx;
+        asm volatile("" : "+v"(rx));
+        const uint32_t ad = g_row + (uint32_t)(16 * (((2 * kk) & 15) ^ rx) + 16 * ((2 * kk) & ~15));
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) a[pc] = *(lp8)(uintptr_t)(ad + (uint32_t)(pc * GIMG));
       };
-      bf16x8_t a[3], an[3], b[3];
-      g_frag(0, a);
+      // half h of the split of V step kk: values 4 h .. 4 h + 3 -> words 2 h, 2 h + 1 of the three piece fragments
+      auto v_split_half = [&](int kk, int h, u32x4_t (&w)[3]) {
 #pragma unroll
-      for (int kk = 0; kk < CT / 16; ++kk) {
-        if (kk + 1 < CT / 16) g_frag(kk + 1, an);
+        for (int e = 2 * h; e < 2 * h + 2; ++e) {
+          uint32_t w0, w1, w2;
+          split3_pair(vfrag[kk][2 * e], vfrag[kk][2 * e + 1], w0, w1, w2);
+          w[0][e] = w0, w[1][e] = w1, w[2][e] = w2;
+        }
+      };
+      // The V values must not look loop-invariant to the optimiser: it would hoist all 192 piece registers out of the tile loop and
+      // spill.  An empty asm that "modifies" them is free only while the value stays in the register class the constraint names: the
+      // accumulators take 192 of the 256 AGPRs, so half of the V fragments live in VGPRs ("+v") and half in the remaining AGPRs ("+a";
+      // with "+v" on all of them each use cost a v_accvgpr_read AND a v_accvgpr_write back)
+      auto v_touch = [&](int kk) {
         if constexpr (!HOIST_V) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(vfrag[kk][j]));  // not loop-invariant for the optimiser: it would hoist all 192 piece registers out of the tile loop and spill
+          for (int j = 0; j < 8; ++j) {
+            if (kk < (CT / 16) / 2)
+              asm volatile("" : "+v"(vfrag[kk][j]));
+            else
+              asm volatile("" : "+a"(vfrag[kk][j]));
+          }
         }
-        split3_bf16(vfrag[kk], b);
-        dp = mfma_x6(a, b, dp);
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const float p = __expf(sp[r] - lse_i[qi]);
-      sp[r] = p;
-      if constexpr (FULL) dp[r] = p * (dp[r] - del_i[qi]);
-    }
-    // ---- dV^T[c][key] += gO^T[c][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key];  dS pieces -> private transposed image
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t pp[3], ds[3];
-      {
-        const float f[8] = {sp[8 * s], sp[8 * s + 1], sp[8 * s + 2], sp[8 * s + 3], sp[8 * s + 4], sp[8 * s + 5], sp[8 * s + 6], sp[8 * s + 7]};
-        split3_bf16(f, pp);
+      };
+      auto ds_make = [&](int s, bf16x8_t (&ds)[3]) {
         const float e[8] = {dp[8 * s], dp[8 * s + 1], dp[8 * s + 2], dp[8 * s + 3], dp[8 * s + 4], dp[8 * s + 5], dp[8 * s + 6], dp[8 * s + 7]};
-        if constexpr (FULL) split3_bf16(e, ds);
-      }
+        split3_bf16(e, ds);
 #pragma unroll
-      for (int pc = 0; pc < (FULL ? 3 : 0); ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
-        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) u32x2_t* lpu2;
-        const u32x4_t w = __builtin_bit_cast(u32x4_t, ds[pc]);
-        *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s) | lh) ^ t_wx))) = u32x2_t{w[0], w[1]};      // g = 2 s
-        *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s + 2) | lh) ^ t_wx))) = u32x2_t{w[2], w[3]};  // g = 2 s + 1
-      }
-      {
-        auto gt_frag = [&](int c, bf16x8_t (&a)[3]) {
-          const uint32_t ch0 = (uint32_t)(16 * (((4 * c) & 15) ^ g_tx) + 16 * ((4 * c) & ~15));
-          const uint32_t ch1 = (uint32_t)(16 * (((4 * c) & 15) ^ g_tx ^ 2) + 16 * ((4 * c) & ~15));
+        for (int pc = 0; pc < 3; ++pc) {  // registers 8 s .. 8 s + 3 are queries 16 s + 4 lh .., registers 8 s + 4 .. + 7 queries 16 s + 8 + 4 lh ..
+          typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(3))) u32x2_t* lpu2;
+          const u32x4_t w = __builtin_bit_cast(u32x4_t, ds[pc]);
+          *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s) | lh) ^ t_wx))) = u32x2_t{w[0], w[1]};      // g = 2 s
+          *(lpu2)(uintptr_t)(t_wr + (uint32_t)(pc * TIMG + 8 * (((4 * s + 2) | lh) ^ t_wx))) = u32x2_t{w[2], w[3]};  // g = 2 s + 1
+        }
+      };
+      auto qt_frag = [&](int s, bf16x8_t (&aq)[NDT][3]) {
+#pragma unroll
+        for (int c = 0; c < NDT; ++c)
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc)
-            a[pc] = tr2(g_tr + (uint32_t)(pc * GIMG + 16 * s * GP) + ch0, g_tr + (uint32_t)(pc * GIMG + (16 * s + 8) * GP) + ch1);
-        };
-        bf16x8_t a[3], an[3];
-        gt_frag(DVLO, a);
+            aq[c][pc] = tr2_nowait(q_tr + (uint32_t)(pc * QIMG + 16 * s * QP + 64 * c), q_tr + (uint32_t)(pc * QIMG + (16 * s + 8) * QP + 64 * c));
+      };
+      bf16x8_t aq0[NDT][3], aq1[NDT][3], ds0[3], ds1[3];
+      constexpr int NDP = CT / 16, NDV = 2 * DVN;   // NDV <= NDP: the dV step of the tile (s, c) = (j / DVN, j % DVN) rides on dP step j
+      static_assert(NDV <= NDP, "dV steps ride on the dP steps");
+      // A step has two halves of six MFMAs.  First half: dP with the fragments a (gO rows) and b (V pieces) made during the step before;
+      // the gO^T fragment t of this step's dV tile is read at its start.  Second half: dV with t; a is dead by then and receives the gO
+      // rows of step kk + 1.  The split of V step kk + 1 is spread over both halves, four vector instructions behind each MFMA (an MFMA
+      // gap hides vector issue only while it stays within its 32 cycles: about five instructions; left alone the scheduler puts 9 - 16
+      // of them between two MFMAs and then issues five MFMAs back to back -- 537 cycles a step against 384 of MFMA, stamps)
+      bf16x8_t a[3], b[3], t[3];
+      u32x4_t wn[3];
+      g_frag(0, a);
+      v_touch(0);
+      v_split_half(0, 0, wn);
+      v_split_half(0, 1, wn);
 #pragma unroll
-        for (int c = 0; c < DVN; ++c) {
-          if (c + 1 < DVN) gt_frag(DVLO + c + 1, an);
-          acc_dv[c] = mfma_x6(a, pp, acc_dv[c]);
+      for (int pc = 0; pc < 3; ++pc) b[pc] = __builtin_bit_cast(bf16x8_t, wn[pc]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < NDP; ++kk) {
+        if (kk < NDV) gt_frag(kk / DVN, DVLO + kk % DVN, t);
+        if (kk + 1 < NDP) {
+          v_touch(kk + 1);
+          v_split_half(kk + 1, 0, wn);
+        }
+        dp = mfma_x6(a, b, dp);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < NDV) pin3(t);
+        if (kk + 1 < NDP) {
+          g_frag(kk + 1, a);
+          v_split_half(kk + 1, 1, wn);
+        }
+        if (kk < NDV) acc_dv[kk < NDV ? kk % DVN : 0] = mfma_x6(t, pp[kk < NDV ? kk / DVN : 0], acc_dv[kk < NDV ? kk % DVN : 0]);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) b[pc] = __builtin_bit_cast(bf16x8_t, wn[pc]);
+      }
+    ATT_STAMP(2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = sp[r] * (dp[r] - del_i[(r & 3) + 8 * (r >> 2) + 4 * lh]);
+    ATT_STAMP(3);
+      qt_frag(0, aq0);
+      ds_make(0, ds0);
+      // ---- dK^T[d][key] += Q^T[d][q] dS[q][key];  dS pieces -> private transposed image (A operand of dQ below).
+      // The pieces of the second 16-query half are split and stored behind the MFMAs of the first half, and the next query tile's
+      // global loads (address arithmetic: ~70 vector instructions) are issued behind the MFMAs of the second half: their 40 staging
+      // registers are live from here on only -- across the dP / dV loop they would not fit (82 registers went to scratch)
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) pin3(aq0[c]);
+      __builtin_amdgcn_sched_barrier(0);
+      qt_frag(1, aq1);
+      ds_make(1, ds1);
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) acc_dk[c] = mfma_x6(aq0[c], ds0, acc_dk[c]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6 * NDT, 0);
+#pragma unroll
+      for (int g = 0; g < 6 * NDT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) pin3(aq1[c]);
+    ATT_STAMP(4);
+      gload(i0 + 32 < T ? i0 + 32 : i0);
+#pragma unroll
+      for (int c = 0; c < NDT; ++c) acc_dk[c] = mfma_x6(aq1[c], ds1, acc_dk[c]);
+#pragma unroll
+      for (int g = 0; g < 6 * NDT; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // ---- second pass over the other channels: P, then dV^T[c][key] += gO^T[c][q] P[q][key] alone
+    ATT_STAMP(2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sp[r] = __expf(sp[r] - lse_i[(r & 3) + 8 * (r >> 2) + 4 * lh]);
+    ATT_STAMP(3);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8_t pp[3];
+        const float f[8] = {sp[8 * s], sp[8 * s + 1], sp[8 * s + 2], sp[8 * s + 3], sp[8 * s + 4], sp[8 * s + 5], sp[8 * s + 6], sp[8 * s + 7]};
+        split3_bf16(f, pp);
+        bf16x8_t a[3], an[3];
+        gt_frag(s, DVLO, a);
+        pin3(a);
+#pragma unroll
+        for (int j = 0; j < DVN; ++j) {  // fragment j + 1 is read before the MFMAs of fragment j are issued and pinned after them
+          if (j + 1 < DVN) gt_frag(s, DVLO + j + 1, an);
+          __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks the reads below the MFMAs, right in front of their wait
+          acc_dv[j] = mfma_x6(a, pp, acc_dv[j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + 1 < DVN) pin3(an);
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) a[pc] = an[pc];
         }
       }
-#pragma unroll
-      for (int c = 0; c < (FULL ? NDT : 0); ++c) {
-        bf16x8_t a[3];
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          a[pc] = tr2(q_tr + (uint32_t)(pc * QIMG + 16 * s * QP + 64 * c), q_tr + (uint32_t)(pc * QIMG + (16 * s + 8) * QP + 64 * c));
-        acc_dk[c] = mfma_x6(a, ds, acc_dk[c]);
-      }
     }
-    // the next query tile's loads are issued only here: their 40 staging registers would otherwise be live across the dP / dV phases,
-    // where the V fragments, the accumulators and the piece fragments already take the whole file (82 registers went to scratch)
-    __builtin_amdgcn_sched_barrier(0);
-    gload(i0 + 32 < T ? i0 + 32 : i0);
+    if constexpr (!FULL) {
+    ATT_STAMP(4);
+      __builtin_amdgcn_sched_barrier(0);
+      gload(i0 + 32 < T ? i0 + 32 : i0);
+    }
     if constexpr (FULL) {
       // ---- query side: dQ[q][d] = dS[q][key] K[key][d] for this wave's keys
+    ATT_STAMP(5);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the transposed image was written by this wave; a wave's LDS operations complete in order
       f32x16 dqs[NDT];
+      auto dq_frag = [&](int j, bf16x8_t (&a)[3], bf16x8_t (&b)[3]) {  // step j = (c, s)
+        const int c = j >> 1, s = j & 1;
   #pragma unroll
-      for (int c = 0; c < NDT; ++c) {
-        f32x16 dq;
-  #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-  #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8_t a[3], b[3];
-  #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
-            a[pc] = tr2(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
-                        t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
-          }
-  #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
-            b[pc] = tr2(k_tr + (uint32_t)(pc * KIMG + 16 * s * KP + 64 * c), k_tr + (uint32_t)(pc * KIMG + (16 * s + 4) * KP + 64 * c));
-          dq = mfma_x6(a, b, dq);
+        for (int pc = 0; pc < 3; ++pc) {
+          a[pc] = tr2_nowait(t_tr + (uint32_t)(pc * TIMG + 16 * s * 64 + 8 * ((4 * gb + tp) ^ t_rx)),
+                             t_tr + (uint32_t)(pc * TIMG + (16 * s + 4) * 64 + 8 * ((4 * gb + tp) ^ (t_rx + 2))));
         }
-        dqs[c] = dq;
+  #pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          b[pc] = tr2_nowait(k_tr + (uint32_t)(pc * KIMG + 16 * s * KP + 64 * c), k_tr + (uint32_t)(pc * KIMG + (16 * s + 4) * KP + 64 * c));
+      };
+      bf16x8_t a[3], b[3], an[3], bn[3];
+      dq_frag(0, a, b);
+      pin3(a);
+      pin3(b);
+  #pragma unroll
+      for (int j = 0; j < 2 * NDT; ++j) {  // same pipeline as above: the fragments of step j + 1 are in flight while step j multiplies
+        if (j + 1 < 2 * NDT) dq_frag(j + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((j & 1) == 0) {
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) dqs[j >> 1][r] = 0.f;
+        }
+        dqs[j >> 1] = mfma_x6(a, b, dqs[j >> 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < 2 * NDT) {
+          pin3(an);
+          pin3(bn);
+        }
+  #pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          a[pc] = an[pc];
+          b[pc] = bn[pc];
+        }
       }
+    ATT_STAMP(6);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's transposed reads of its dS^T image are done: the partial tiles may overwrite it
   #pragma unroll
       for (int c = 0; c < NDT; ++c)
   #pragma unroll
         for (int r = 0; r < 16; ++r) RBw[(c * 16 + r) * 64 + lane] = dqs[c][r];
+    ATT_STAMP(7);
       __syncthreads();   // every wave is done with the query tile; the four slots hold the partial dQ tiles
-      // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics
+    ATT_STAMP(8);
+      // sum the partials: NDT*16 register-rows in all, wave w takes rows [w*NDT*4, (w+1)*NDT*4) and issues the atomics.  All the partials
+      // are read first; the next query tile's pieces are split and stored while they are in flight (every wave is past the barrier, so
+      // nobody reads the gO / Q images any more), then the sums and the atomics follow
+      float part[NDT * 4][4];
+  #pragma unroll
+      for (int rr = 0; rr < NDT * 4; ++rr)
+  #pragma unroll
+        for (int w = 0; w < 4; ++w) part[rr][w] = reinterpret_cast<const float*>(Ts + w * WSLOT)[(wid * NDT * 4 + rr) * 64 + lane];
+    ATT_STAMP(9);
+      lstore();
+    ATT_STAMP(10);
   #pragma unroll
       for (int rr = 0; rr < NDT * 4; ++rr) {
         const int row = wid * NDT * 4 + rr;       // = c*16 + r
         const int c = row >> 4, r = row & 15;
         float sum = 0.f;
   #pragma unroll
-        for (int w = 0; w < 4; ++w) sum += reinterpret_cast<const float*>(Ts + w * WSLOT)[(c * 16 + r) * 64 + lane];
+        for (int w = 0; w < 4; ++w) sum += part[rr][w];
         atomicAdd(gq + ((int64_t)n * T + i0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * D + c * 32 + l31, sum);
       }
     } else {
       __syncthreads();   // every wave is done with the query tile
+      lstore();
     }
-    lstore();
     __syncthreads();
+    ATT_STAMP(11);
   }
 
   // all query-side atomics of this workgroup have COMPLETED before its key-side ones start: where both touch one row (the last query
