@@ -48,6 +48,7 @@ SIGNATURES = {
     "fmi_gather_u8_i64": [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "fmi_u8_lut_chw_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "fmi_split3_f32": [vp, vp, vp, i64, i32, i32, f32, vp],
+    "fmi_split3_colsum_f32": [vp, vp, vp, i64, i32, vp],
     "fmi_merge3_f32": [vp, vp, i64, i32, vp],
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],

@@ -44,6 +44,47 @@ extern "C" int fmi_split3_f32(const float* x, void* x3, float* y, int64_t pixels
   return fmi_launch_status();
 }
 
+// The same pass over a gradient tensor dy also yields the bias gradient colsum[c] += sum over pixels dy[pixel][c] (the weight gradient with
+// both operands as pieces no longer reads the fp32 dy, so its fused bias gradient went away and a separate pass re-read dy: 1.4 ms of
+// the C2 step).  The grid stride is a multiple of C / 8, so a thread keeps ONE 8-channel chunk: eight running sums, then one LDS and one
+// global atomic round per workgroup.  Not for the reproducible mode (atomics): the caller takes fmi_bias_grad_f32 there.
+__global__ void __launch_bounds__(256) split3_colsum_kernel(const float* __restrict__ x, uint16_t* __restrict__ x3, float* __restrict__ colsum, int64_t n8, int C) {
+  __shared__ float part[512];
+  for (int c = threadIdx.x; c < C; c += 256) part[c] = 0.f;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int cpr = C >> 3;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int64_t i = i0; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    s[0] += a.x, s[1] += a.y, s[2] += a.z, s[3] += a.w, s[4] += b.x, s[5] += b.y, s[6] += b.z, s[7] += b.w;
+    uint32_t w[3][4];
+    split3_pair(a.x, a.y, w[0][0], w[1][0], w[2][0]);
+    split3_pair(a.z, a.w, w[0][1], w[1][1], w[2][1]);
+    split3_pair(b.x, b.y, w[0][2], w[1][2], w[2][2]);
+    split3_pair(b.z, b.w, w[0][3], w[1][3], w[2][3]);
+    uint16_t* q = x3 + (i >> 1) * 48 + (i & 1) * 8;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(q + pc * 16) = make_uint4(w[pc][0], w[pc][1], w[pc][2], w[pc][3]);
+  }
+  __syncthreads();
+  const int ch = (int)(i0 % cpr) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(&part[ch + e], s[e]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(colsum + c, part[c]);
+}
+
+extern "C" int fmi_split3_colsum_f32(const float* x, void* x3, float* colsum, int64_t pixels, int C, void* stream) {
+  if (!x || !x3 || !colsum || pixels <= 0 || C <= 0 || (C & 15)) return FMI_ERR_BAD_ARG;
+  if (((uintptr_t)x & 15) || ((uintptr_t)x3 & 15)) return FMI_ERR_BAD_ARG;
+  if (C > 512 || 256 % (C >> 3) != 0) return FMI_ERR_UNSUPPORTED;  // a thread must stay on one channel chunk
+  const int64_t n8 = pixels * (C >> 3);
+  int grid = fmi_bw_grid(n8, 256);
+  if (grid > 1024) grid = 1024;  // C atomics per workgroup
+  hipLaunchKernelGGL(split3_colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)x3, colsum, n8, C);
+  return fmi_launch_status();
+}
+
 // inverse (tests, debugging): y = x0 + x1 + x2, added in fp32 from the smallest piece up (exact: the sum has at most 24 significant bits)
 __global__ void __launch_bounds__(256) merge3_kernel(const uint16_t* __restrict__ x3, float* __restrict__ y, int64_t n, int C) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

@@ -186,9 +186,10 @@ def p3_wanted(pixels: int, cred: int, cout: int, taps: int) -> bool:
     return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= 64 and pixels >= P3_MIN_PIXELS and taps * cout >= P3_MIN_WORK
 
 
-def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: float = 0.0) -> Optional[torch.Tensor]:
+def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: float = 0.0, colsum: Optional[list] = None) -> Optional[torch.Tensor]:
     """piece image of the dense NHWC fp32 tensor t (cached on t).  lrelu_from: t is still EMPTY and becomes lrelu(lrelu_from, slope) in the
-    same pass that cuts its pieces."""
+    same pass that cuts its pieces.  colsum: an empty list; when the pass over t (a gradient) actually runs here it also sums t over the
+    pixels -- the bias gradient -- and the [C] tensor is appended (not in the reproducible mode: that sum uses atomics)."""
     c = t.shape[-1]
     if c % 16 or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.data_ptr() % 16:
         if lrelu_from is not None:
@@ -200,6 +201,10 @@ def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: flo
     x3 = torch.empty(t.numel() * 3, device=t.device, dtype=torch.bfloat16)
     if lrelu_from is not None:
         _L().split3_f32(_p(lrelu_from), C.c_void_p(x3.data_ptr()), _p(t), t.numel() // c, c, 1, float(slope), _st())
+    elif colsum is not None and c <= 512 and 256 % (c // 8) == 0 and not _L().get_deterministic():
+        gb = _zeros(c, t.device, torch.float32)
+        _L().split3_colsum_f32(_p(t), C.c_void_p(x3.data_ptr()), _p(gb), t.numel() // c, c, _st())
+        colsum.append(gb)
     else:
         _L().split3_f32(_p(t), C.c_void_p(x3.data_ptr()), None, t.numel() // c, c, 0, 0.0, _st())
     t._fmi_p3 = (x3, t._version)
@@ -377,6 +382,7 @@ class _Conv2d(torch.autograd.Function):
         gx = gwf = gb = gres = None
         masked = False
         dil = ctx.dil
+        gb_of_split = [] if (ctx.has[0] and ctx.needs_input_grad[2]) else None  # filled by the pass that cuts dy's pieces, if one runs
         if ctx.needs_input_grad[0]:
             d0, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode, dil=dil)
             if pad_mode == 1 and lib.conv2d_thin_supported(C.byref(d0)):  # thin output: adjoint and fold in one pass
@@ -393,7 +399,7 @@ class _Conv2d(torch.autograd.Function):
                 lib.reflect_pad_fold_f32(_p(gpad), _p(gx), n, h, w, c, pad, _st())
             else:
                 oh_, ow_ = gy.shape[1], gy.shape[2]
-                gy3 = p3_of(gy) if (ctx.wt3 is not None and p3_wanted(n * oh_ * ow_, k, c, kh * kw)) else None
+                gy3 = p3_of(gy, colsum=gb_of_split) if (ctx.wt3 is not None and p3_wanted(n * oh_ * ow_, k, c, kh * kw)) else None
                 d, _, _ = conv_desc(n, h, w, c, k, kh, kw, stride, pad, dil=dil, w3=ctx.wt3, x3=gy3)
                 gx = torch.empty_like(x)
                 with _prof(f"conv_dgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
@@ -421,7 +427,7 @@ class _Conv2d(torch.autograd.Function):
             # both operands as piece images (x's from the forward, dy's shared with the adjoint above): the weight gradient runs without
             # split arithmetic; the bias gradient then takes its own pass
             if ctx.x3 is not None and pad_mode == 0 and c % 32 == 0 and k % 16 == 0 and p3_wanted(gy.numel() // k, c, k, kh * kw):
-                gy3 = p3_of(gy)
+                gy3 = p3_of(gy, colsum=gb_of_split)
                 if gy3 is not None:
                     d.w3 = None
                     d.x3, d.y3 = ctx.x3.data_ptr(), gy3.data_ptr()
@@ -436,8 +442,11 @@ class _Conv2d(torch.autograd.Function):
             with _prof(f"conv_wgrad|{n}x{h}x{w} {c}->{k} k{kh}s{stride}", 2.0 * gy.numel() * c * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(x), _p(gy), _p(gwf), _p(gb) if fuse else None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2] and gb is None:
-            gb = _zeros(k, x.device, torch.float32)
-            lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
+            if gb_of_split:  # summed by the pass that cut dy's pieces
+                gb = gb_of_split[0]
+            else:
+                gb = _zeros(k, x.device, torch.float32)
+                lib.bias_grad_f32(_p(gy), gy.numel() // k, k, k, _p(gb), _st())
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
         return gx, gwf, gb, gres, None, None, None, None, None, None, None, None, None, None, None, None
@@ -710,22 +719,23 @@ class _ConvTranspose2d(torch.autograd.Function):
         cb = wf.shape[1]
         d, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=ctx.wf3)
         gx = gwf = gb = gres = None
+        gb_of_split = [] if (ctx.has[0] and ctx.needs_input_grad[2]) else None  # filled by the pass that cuts dy's pieces, if one runs
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            gy3 = p3_of(gy) if (ctx.wf3 is not None and p3_wanted(n * H * W, cb, cs, kh * kw)) else None
+            gy3 = p3_of(gy, colsum=gb_of_split) if (ctx.wf3 is not None and p3_wanted(n * H * W, cb, cs, kh * kw)) else None
             d0, _, _ = conv_desc(n, H, W, cb, cs, kh, kw, stride, pad, w3=ctx.wf3, x3=gy3)
             with _prof(f"convT_dgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_fwd_f32(C.byref(d0), _p(gy), _p(wf), None, None, _p(gx), 0, 1, 0, _st())
         if ctx.needs_input_grad[1]:
             gwf = _zeros_like(wf)
             if ctx.x3 is not None and cb % 32 == 0 and cs % 16 == 0:  # the big image's pieces (shared with the adjoint above) and x's from the forward
-                gy3 = p3_of(gy)
+                gy3 = p3_of(gy, colsum=gb_of_split)
                 if gy3 is not None:
                     d.x3, d.y3 = gy3.data_ptr(), ctx.x3.data_ptr()
             with _prof(f"convT_wgrad|{n}x{h}x{w} {cs}->{cb}", 2.0 * x.numel() * cb * kh * kw):
                 lib.conv2d_wgrad_f32(C.byref(d), _p(gy), _p(x), _p(gwf), None, 1, 0, _st())
         if ctx.has[0] and ctx.needs_input_grad[2]:
-            gb = _bias_grad_of(gy, cb)
+            gb = gb_of_split[0] if gb_of_split else _bias_grad_of(gy, cb)
         if ctx.has[1] and ctx.needs_input_grad[3]:
             gres = gy
         return gx, gwf, gb, gres, None, None, None, None, None, None, None

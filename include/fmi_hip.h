@@ -117,6 +117,10 @@ int fmi_u8_lut_chw_f32(const uint8_t* in, const float* lut256, float* out, int N
  * base_function.py:207-305).  y (may be NULL): also receives the fp32 value the pieces were cut from.  fmi_merge3_f32 is the inverse. */
 int fmi_split3_f32(const float* x, void* x3, float* y, int64_t pixels, int C, int op, float p0, void* stream);
 int fmi_merge3_f32(const void* x3, float* y, int64_t pixels, int C, void* stream);
+/* pieces of a gradient tensor dy AND its bias gradient in the same pass: colsum[c] += sum over pixels dy[pixel][c] (fp32 atomics; the
+ * reproducible mode takes fmi_bias_grad_f32 instead).  C <= 512 and 256 % (C / 8) == 0, else FMI_ERR_UNSUPPORTED.  Replaces the bias
+ * term of Conv2d's backward (torch.nn.Conv2d in base_function.py:207-305) when the weight gradient reads dy as pieces. */
+int fmi_split3_colsum_f32(const float* x, void* x3, float* colsum, int64_t pixels, int C, void* stream);
 
 /* y = conv(x, wf) + bias[k] + residual ; bias/residual may be NULL.
  * act: 0 none, 1 tanh, 2 relu, applied last. residual has y's layout. */

@@ -69,6 +69,47 @@ def test_split3_pieces_are_exact(dev, FF, shape):
     assert torch.equal((y0.double() + y1.double() + y2.double()).float(), ref)
 
 
+@pytest.mark.parametrize("pixels,c", [(4096, 64), (777, 32), (33, 512), (5000, 16), (300, 256)])
+def test_split3_with_bias_gradient(dev, FF, pixels, c):
+    """fmi_split3_colsum_f32: the piece image is the one fmi_split3_f32 writes, bit for bit, and colsum += the sum over the pixels (fp32 partial
+    sums per thread and workgroup: 2e-6 of sum |dy| against float64); shapes a thread cannot keep one channel chunk for are refused; and Conv2d's
+    backward takes the bias gradient from it (against fmi_bias_grad_f32 through the reproducible mode)"""
+    g = torch.Generator().manual_seed(pixels + c)
+    x = torch.randn(pixels, c, generator=g).to(dev)
+    ref3, _ = _split(FF, x)
+    x3 = torch.zeros_like(ref3)
+    cs = torch.full((c,), 1.0, device=dev)
+    _lib().split3_colsum_f32(FF._p(x), C.c_void_p(x3.data_ptr()), FF._p(cs), pixels, c, FF._st())
+    assert torch.equal(x3, ref3)
+    want = x.double().sum(0) + 1.0
+    assert float((cs.double() - want).abs().max()) <= 2e-6 * float(x.double().abs().sum(0).max())
+
+
+def test_split3_with_bias_gradient_refusals_and_autograd(dev, FF):
+    from face_mask_inpaint_amd._lib import FmiError
+
+    x = torch.zeros(8, 48, device=dev)
+    x3 = torch.zeros(8 * 48 * 3, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(FmiError):  # 256 % (48 / 8) != 0
+        _lib().split3_colsum_f32(FF._p(x), C.c_void_p(x3.data_ptr()), FF._p(torch.zeros(48, device=dev)), 8, 48, FF._st())
+    g = torch.Generator().manual_seed(3)
+    xin = torch.randn(2, 96, 96, 64, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = torch.zeros(128, device=dev, requires_grad=True)
+    up = torch.randn(2, 96, 96, 128, generator=g).to(dev)
+    grads = {}
+    for det in (False, True):
+        with FF.deterministic(det):
+            for t in (xin, w, b):
+                t.grad = None
+            (pw,) = FF.prepare_weights([(w, None, None)])
+            (FF.conv2d(xin, pw, b, pad=1) * up).sum().backward()
+            grads[det] = b.grad.clone()
+    want = up.double().sum((0, 1, 2))
+    for det in (False, True):
+        assert float((grads[det].double() - want).abs().max()) <= 2e-6 * float(up.double().abs().sum((0, 1, 2)).max())
+
+
 def test_split3_argument_checks(dev, FF):
     x = torch.zeros(4, 24, device=dev)
     x3 = torch.zeros(4 * 24 * 3, device=dev, dtype=torch.bfloat16)

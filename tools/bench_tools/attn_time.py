@@ -25,4 +25,13 @@ e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 4
 fl = 2.0 * n * t * t * (d + c) + 2.0 * n * t * t * (3 * d + 2 * c)
-print(f"fwd+bwd {ms:.2f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+with torch.no_grad():
+    FF.self_attention(q, [v])
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(4):
+        FF.self_attention(q, [v])
+    e.record()
+    torch.cuda.synchronize()
+fwd = s.elapsed_time(e) / 4
+print(f"fwd {fwd:.2f} ms  bwd {ms - fwd:.2f} ms  fwd+bwd {ms:.2f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
