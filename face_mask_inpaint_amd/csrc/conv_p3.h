@@ -670,6 +670,269 @@ using WG3_128x64 = P3Tile<2, 2, 2, 1>;
 using WG3_128x32 = P3Tile<4, 1, 1, 1>;
 using WG3_256x128 = P3Tile<4, 2, 2, 2>;  // 8 waves
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3 x 3 stride-1 zero-padded weight gradient with TAP REUSE along x.  The kernel above stages x once per tap: a 128 x 128 tile moves
+// 24 KB per 16-pixel step for 768 matrix cycles = 32 B/clk/CU, more than the L2 -> LDS path delivers (24 - 28).  Here a tile is one
+// kernel ROW: its rows are (kx = 0..2) x (32 GA channels), its A image holds the 16 pixels of the step PLUS ONE on either side, at
+// image row y + ky - 1, and the fragments of the three kx taps are read from it at pixel offsets -1 / 0 / +1 (a transposed read
+// addresses its four pixel rows per lane, so the two outer pixels may live in a separate "halo" strip that one partial wave
+// instruction fills).  GA = 2, 128 columns: 19 KB per step for 1152 matrix cycles per SIMD = 17 B/clk/CU.  Measured against the
+// kernel above (one box): 256 -> 128 at 128^2 175 vs 153 TFLOP/s, 128 -> 64 at 256^2 154 vs 125, 128 -> 128 at 64^2 123 vs 98.  Two
+// workgroups per CU are essential (launch bounds: 268 -> 256 registers; at one workgroup per CU it LOSES to the kernel above).
+//   What the shifted rows must not see is the pixel of the neighbouring image row where x - 1 / x + 1 leaves the image: the pixel is
+// the REDUCTION index here (an element of the fragment registers, the same for every lane), so the one pixel of a step with x = 0
+// (kx = 0) or x = W - 1 (kx = 2) -- at most one each, W >= 16 -- is cleared in the A fragments by a wave-uniform mask.
+//   LDS stage: [3 GA images (piece, 32-channel group)][16 pixels][32 ch] | halo [3 GA][2][32 ch] | B [3 GB images][16 pixels][32 cols].
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Wg3x3Args {
+  const uint16_t* x3;
+  const uint16_t* dy3;
+  float* dwf;
+  int H, W, C, Kout, P, kchunk, ksplit, tiles, xcd_splits;
+  FastDiv dW, dHW;
+};
+
+template <int GA, int TN, bool FL = false>
+__global__ void __launch_bounds__(256, FL ? 1 : 2) wgrad3x3_p3_kernel(Wg3x3Args a, int tiles_n) {
+  constexpr int NW = 4, WN = 4 / GA, BN = WN * TN * 32, GB = BN / 32, BK = 16;
+  constexpr int NIA = 3 * GA, NIB = 3 * GB, NI = NIA + NIB + 1;  // main A images, B images, one halo instruction
+  constexpr int NL = (NI + NW - 1) / NW;
+  constexpr int HALO = NIA * 1024, BOFF = HALO + 1024, STAGE = BOFF + NIB * 1024;  // the halo strip takes 3 GA * 128 bytes of its KiB
+  static_assert(NIA * 8 <= 64, "one wave instruction fills the halo strip");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int lid, split;
+  if (a.xcd_splits) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int grp = idx / a.tiles;
+    lid = idx - grp * a.tiles;
+    split = grp * 8 + xcd;
+    if (split >= a.ksplit) return;
+  } else {
+    lid = xcd_remap(blockIdx.x, gridDim.x);
+    split = blockIdx.y;
+  }
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int cgs = a.C / (32 * GA);
+  const int ky = tile_m / cgs, cb = (tile_m - ky * cgs) * 32 * GA;  // kernel row, first channel
+  const int n0 = tile_n * BN;
+  const int wm = wid / WN, wn = (wid % WN) * TN * 32;              // this wave: channel group wm, columns wn ..
+  const int k_begin = split * a.kchunk;
+  int k_end = k_begin + a.kchunk;
+  if (k_end > a.P) k_end = a.P;
+  const int HW = a.H * a.W;
+
+  // copy slots: instruction ii = j * NW + wid of [A main: 3 GA][B: 3 GB][halo].  Branch-free per step: a slot is (base, pixel pitch, offset,
+  // which of the thread's two tracked pixels, whether the image row must be inside) -- the thread tracks (x, y) of its main pixel
+  // k0 + pl and of its halo pixel (k0 - 1 or k0 + 16 by lane) incrementally, 16 pixels a step, W >= 16
+  const int pl = lane >> 2, cq = lane & 3;
+  const uint16_t* s_base[NL];
+  int s_pitch[NL];
+  int64_t s_off[NL];
+  bool s_on[NL], s_halo[NL], s_row[NL];
+  uint32_t s_dst[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int ii = j * NW + wid;
+    s_base[j] = a.x3, s_pitch[j] = 3 * a.C, s_off[j] = 0, s_on[j] = false, s_halo[j] = false, s_row[j] = false;
+    uint32_t dst = 0;
+    if (ii < NIA) {
+      const int piece = ii / GA, ch = cb + 32 * (ii - piece * GA) + 8 * cq;
+      s_on[j] = true, s_row[j] = true;
+      s_off[j] = (int64_t)(ky - 1) * a.W * (3 * a.C) + (ch >> 4) * 48 + piece * 16 + ((ch >> 3) & 1) * 8;
+      dst = (uint32_t)(ii * 1024);
+    } else if (ii < NIA + NIB) {
+      const int q = ii - NIA, piece = q / GB, col = n0 + 32 * (q - piece * GB) + 8 * cq;
+      s_base[j] = a.dy3, s_pitch[j] = 3 * a.Kout;
+      s_on[j] = col < a.Kout;
+      s_off[j] = (col >> 4) * 48 + piece * 16 + ((col >> 3) & 1) * 8;
+      dst = (uint32_t)(BOFF + q * 1024);
+    } else if (ii == NIA + NIB) {
+      const int img = lane >> 3, piece = img / GA, ch = cb + 32 * (img - piece * GA) + 8 * cq;  // lane = img * 8 + side * 4 + cq
+      s_on[j] = img < NIA, s_halo[j] = true, s_row[j] = true;
+      s_off[j] = (int64_t)(ky - 1) * a.W * (3 * a.C) + (ch >> 4) * 48 + piece * 16 + ((ch >> 3) & 1) * 8;
+      dst = (uint32_t)HALO;
+    }
+    s_dst[j] = __builtin_amdgcn_readfirstlane(dst);
+  }
+  const int n_w = (NI - wid + NW - 1) / NW;
+
+  f32x16 acc[3][TN];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  // tracked pixels: main = k_begin + pl, halo = k_begin - 1 / + 16; (x, y) of each, y = image row of the OUTPUT pixel
+  const int hdp = ((lane >> 2) & 1) ? 16 : -1;
+  int pm = k_begin + pl, ph = k_begin + hdp;
+  int xm, ym, xh, yh;
+  {
+    const uint32_t n = fdiv((uint32_t)pm, a.dHW), rem = (uint32_t)pm - n * (uint32_t)HW;
+    ym = (int)fdiv(rem, a.dW), xm = (int)rem - ym * a.W;
+    const int phc = ph < 0 ? 0 : ph;
+    const uint32_t n2 = fdiv((uint32_t)phc, a.dHW), rem2 = (uint32_t)phc - n2 * (uint32_t)HW;
+    yh = (int)fdiv(rem2, a.dW), xh = (int)rem2 - yh * a.W;
+    if (ph < 0) xh = a.W - 1, yh = a.H - 1;  // "pixel -1": one step on it becomes pixel 15 of the first row
+  }
+  auto advance = [&]() __attribute__((always_inline)) {
+    pm += BK, ph += BK;
+    xm += BK, xh += BK;
+    if (xm >= a.W) { xm -= a.W; ym = ym + 1 == a.H ? 0 : ym + 1; }
+    if (xh >= a.W) { xh -= a.W; yh = yh + 1 == a.H ? 0 : yh + 1; }
+  };
+  auto issue = [&](int st) __attribute__((always_inline)) {  // copies the step the tracked pixels stand on
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE));
+    const bool vm = pm < k_end, vh = ph >= 0 && ph < a.P;
+    const bool rm = (unsigned)(ym + ky - 1) < (unsigned)a.H, rh = (unsigned)(yh + ky - 1) < (unsigned)a.H;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      if (j >= n_w) break;
+      const int pix = s_halo[j] ? ph : pm;
+      const bool ok = s_on[j] && (s_halo[j] ? vh : vm) && (!s_row[j] || (s_halo[j] ? rh : rm));
+      const void* gp = ok ? (const void*)(s_base[j] + (int64_t)pix * s_pitch[j] + s_off[j]) : (const void*)fmi_chunk_zero;
+      glds16_p3(gp, s0 + s_dst[j]);
+    }
+  };
+  // transposed fragment reads.  Pixel row p of an A image (p = -1 .. 16): main image [16][64 B], p = -1 / 16 in the halo strip.  All
+  // per-lane offsets are loop constants; the stage and the image enter as immediates (the step loop is unrolled over the two stages)
+  const int i16 = lane & 15;
+  const uint32_t lcol = (uint32_t)(32 * ((lane >> 4) & 1) + 8 * (i16 & 3));
+  const int prow = 8 * lh + (i16 >> 2);
+  typedef __attribute__((address_space(3))) p3_s16x4* lp;
+  uint32_t offA[3][2], offA0[3], offA2[3];  // [kx][read]; the two reads that touch the halo strip: per piece
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) offA[kx][r] = lds0 + (uint32_t)(wm * 1024 + (prow + 4 * r + kx - 1) * 64) + lcol;
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) {
+    offA0[pc] = prow - 1 < 0 ? lds0 + (uint32_t)(HALO + (pc * GA + wm) * 128) + lcol : offA[0][0] + (uint32_t)(pc * GA * 1024);
+    offA2[pc] = prow + 5 > 15 ? lds0 + (uint32_t)(HALO + (pc * GA + wm) * 128 + 64) + lcol : offA[2][1] + (uint32_t)(pc * GA * 1024);
+  }
+  const uint32_t offB = lds0 + (uint32_t)(BOFF + (wn / 32) * 1024 + prow * 64) + lcol;
+  auto tr2 = [&](uint32_t a0, uint32_t a1) __attribute__((always_inline)) {
+    union {
+      p3_s16x4 h[2];
+      bf16x8_t v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a1);
+    return u.v;
+  };
+  // clear reduction element q (a pixel of the step, wave-uniform) of an A fragment: lanes of half q >> 3, register (q & 7) >> 1, half-word q & 1
+  auto clear_pixel = [&](bf16x8_t v, int q) __attribute__((always_inline)) {
+    u32x4_t w = __builtin_bit_cast(u32x4_t, v);
+    const uint32_t keep = (q & 1) ? 0x0000ffffu : 0xffff0000u;
+    const uint32_t m = (lh == (q >> 3)) ? keep : 0xffffffffu;
+    const int rq = (q & 7) >> 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] &= (r == rq) ? m : 0xffffffffu;
+    return __builtin_bit_cast(bf16x8_t, w);
+  };
+  auto compute = [&](const int st, int xr) __attribute__((always_inline)) {  // xr = x coordinate of the step's first pixel
+    const uint32_t so = (uint32_t)(st * STAGE);
+    const int ql = xr == 0 ? 0 : a.W - xr;   // the pixel with x = 0 (16 or more: none in this step)
+    const int qr = a.W - 1 - xr;             // the pixel with x = W - 1
+    bf16x8_t pb[TN][3];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const uint32_t ad = offB + so + (uint32_t)((pc * GB + j) * 1024);
+        pb[j][pc] = tr2(ad, ad + 256u);
+      }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      bf16x8_t pa[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const uint32_t im = so + (uint32_t)(pc * GA * 1024);
+        const uint32_t a0 = kx == 0 ? offA0[pc] + so : offA[kx][0] + im;
+        const uint32_t a1 = kx == 2 ? offA2[pc] + so : offA[kx][1] + im;
+        pa[pc] = tr2(a0, a1);
+      }
+      if (kx == 0 && ql < 16) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) pa[pc] = clear_pixel(pa[pc], ql);
+      }
+      if (kx == 2 && qr < 16) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) pa[pc] = clear_pixel(pa[pc], qr);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[kx][j] = mfma_x6(pa, pb[j], acc[kx][j]);
+    }
+  };
+  const int nt = (k_end - k_begin + BK - 1) / BK;
+  if (nt > 0) issue(0);
+  int xr = __builtin_amdgcn_readfirstlane(k_begin - (int)fdiv((uint32_t)k_begin, a.dW) * a.W);  // k_begin mod W (every pixel row has W pixels)
+  f32x16 acc2[FL ? 3 : 1][FL ? TN : 1];
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  }
+  auto step = [&](const int st, int t) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) {
+      advance();
+      issue(st ^ 1);
+    }
+    compute(st, xr);
+    xr += BK;
+    if (xr >= a.W) xr -= a.W;
+    if constexpr (FL) {
+      if ((t & 31) == 31) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] += acc[i][j][r], acc[i][j][r] = 0.f;
+      }
+    }
+  };
+  for (int t = 0; t < nt; t += 2) {
+    step(0, t);
+    if (t + 1 < nt) step(1, t + 1);
+  }
+  if constexpr (FL) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+  }
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (ky * 3 + kx) * a.C + cb + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + j * 32 + l31;
+        if (col < a.Kout) atomicAdd(a.dwf + (int64_t)row * a.Kout + col, acc[kx][j][r]);
+      }
+    }
+  }
+}
+
+// C % 64: with one 32-channel group per tile (GA = 1) the three taps share too little -- measured 47 against 72 TFLOP/s of the kernel above
+static bool wgrad3x3_p3_ok(const fmi_conv_desc* d) {
+  return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->dil <= 1 && d->W >= 16 && d->OH == d->H && d->OW == d->W && d->C % 64 == 0;
+}
+
 // x3 / dy3: piece images of x [N][H][W][C] and dy [N][OH][OW][K] (dense tensors)
 static int launch_wgrad_p3(const fmi_conv_desc* d, const uint16_t* x3, const uint16_t* dy3, float* dwf, hipStream_t st) {
   WgP3Args a{};
@@ -682,7 +945,39 @@ static int launch_wgrad_p3(const fmi_conv_desc* d, const uint16_t* x3, const uin
   g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
   g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
   a.Kout = d->K; a.Mrows = d->kh * d->kw * d->C; a.P = d->N * d->OH * d->OW;
-  static const int tile_dbg = getenv("FMI_WG3_TILE") ? atoi(getenv("FMI_WG3_TILE")) : 0;  // experiment: 1 = the 8-wave 256 x 128 tile
+  static const int tile_dbg = getenv("FMI_WG3_TILE") ? atoi(getenv("FMI_WG3_TILE")) : 0;  // experiment: 1 = the 8-wave 256 x 128 tile, 2 = never the tap-reuse kernel
+  if (tile_dbg != 2 && wgrad3x3_p3_ok(d)) {
+    Wg3x3Args w{};
+    w.x3 = x3; w.dy3 = dy3; w.dwf = dwf;
+    w.H = d->H; w.W = d->W; w.C = d->C; w.Kout = d->K; w.P = d->N * d->H * d->W;
+    w.dW = make_fastdiv(d->W); w.dHW = make_fastdiv(d->H * d->W);
+    const int bn3 = d->K <= 64 ? 64 : 128;
+    const int64_t tm3 = 3 * (d->C / 64), tn3 = ceil_div64(d->K, bn3);
+    int64_t ks = 2048 / (tm3 * tn3);
+    const int64_t kmax3 = w.P / 512;
+    if (ks > kmax3) ks = kmax3;
+    if (ks < 1) ks = 1;
+    if (ks >= 6) ks = (ks + 4) / 8 * 8;
+    if (fmi_det()) ks = 1;
+    w.kchunk = (int)(ceil_div64(ceil_div64(w.P, ks), 16) * 16);
+    ks = ceil_div64(w.P, w.kchunk);
+    w.tiles = (int)(tm3 * tn3);
+    w.ksplit = (int)ks;
+    w.xcd_splits = ks >= 8 ? 1 : 0;
+    const int64_t nwg3 = w.xcd_splits ? tm3 * tn3 * ceil_div64(ks, 8) * 8 : tm3 * tn3;
+    if (nwg3 > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+    const dim3 grid3((unsigned)nwg3, w.xcd_splits ? 1u : (unsigned)ks);
+    const bool fl3 = w.kchunk > 640 && (fmi_det() || fmi_blocked_acc());
+#define WG3X3_LAUNCH(GA_, TN_)                                                                                 \
+  do {                                                                                                         \
+    if (fl3) hipLaunchKernelGGL((wgrad3x3_p3_kernel<GA_, TN_, true>), grid3, dim3(256), 0, st, w, (int)tn3);   \
+    else hipLaunchKernelGGL((wgrad3x3_p3_kernel<GA_, TN_>), grid3, dim3(256), 0, st, w, (int)tn3);             \
+  } while (0)
+    if (bn3 == 128) WG3X3_LAUNCH(2, 2);
+    else WG3X3_LAUNCH(2, 1);
+#undef WG3X3_LAUNCH
+    return fmi_launch_status();
+  }
   const bool big = tile_dbg == 1 && d->K > 64;
   const int bm = big ? 256 : 128;
   const int bn = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);

@@ -209,7 +209,12 @@ def test_autograd_path_takes_the_pieces(dev, FF, monkeypatch):
 
 @pytest.mark.parametrize("n,c,k,h,w,ksz,stride,pad", [(2, 64, 64, 40, 36, 3, 1, 1), (1, 128, 192, 33, 31, 3, 1, 1), (2, 64, 128, 24, 24, 1, 1, 0),
                                                       (2, 64, 64, 32, 32, 3, 2, 1), (1, 32, 64, 20, 20, 3, 1, 1), (1, 64, 32, 64, 64, 3, 1, 1),
-                                                      (8, 128, 128, 64, 64, 3, 1, 1), (1, 96, 48, 17, 19, 3, 1, 1)])
+                                                      (8, 128, 128, 64, 64, 3, 1, 1), (1, 96, 48, 17, 19, 3, 1, 1),
+                                                      # the tap-reuse kernel (3 x 3, stride 1, C % 64 == 0, W >= 16): rows that are not a multiple of the 16-pixel
+                                                      # step (the x = 0 / x = W - 1 masks fall anywhere in a step), the narrowest map, one image row, a pixel count
+                                                      # that is not a multiple of 16, 48 / 144 columns, several images
+                                                      (3, 64, 48, 5, 21, 3, 1, 1), (2, 128, 144, 7, 16, 3, 1, 1), (1, 64, 64, 1, 37, 3, 1, 1), (5, 192, 128, 3, 17, 3, 1, 1),
+                                                      (2, 64, 128, 19, 16, 3, 1, 1)])
 def test_weight_gradient_with_pieces_of_both_operands(dev, FF, n, c, k, h, w, ksz, stride, pad):
     """fmi_conv2d_wgrad_f32 given the piece images of x (d.x3) and of dy (d.y3) against the same entry without them (2e-6 of the largest
     entry: same exact products, another summation order across pixel splits) and against torch fp32 autograd on the CPU (1e-5)"""
