@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -176,14 +177,15 @@ def conv_desc(n, h, w, c, k, kh, kw, stride, pad, pad_mode=0, x_cs=None, y_cs=No
 # ---------------------------------------------------------------------------------------------------
 P3_ENABLED = True
 P3_MIN_PIXELS = 16384  # smaller feature maps are launch / latency bound: the in-wave split costs nothing there
-P3_MIN_WORK = 1152     # taps * output channels per activation element below which a split pass costs more than it returns
+P3_MIN_WORK = int(os.environ.get("FMI_P3_MIN_WORK", "1152"))  # taps * output channels per activation element below which a split pass costs more than it returns
+P3_MIN_COUT = int(os.environ.get("FMI_P3_MIN_COUT", "64"))    # (both overridable for A/B runs: tools/bench_tools/README.md)
 
 
 def p3_wanted(pixels: int, cred: int, cout: int, taps: int) -> bool:
     """is the piece-image path worth one split pass over the activation operand?  (reduction channels cred, output channels cout)"""
     # one split pass moves 10 B per element (2.3 ps at 4.4 TB/s); the convolution spends 2 * taps * cout FLOP per element (3 x 3, 64 outputs:
     # 7.7 ps at 150 TFLOP/s) and gains ~20 % from the pieces: worth it from taps * cout = 1152 up (3 x 3 with 128 outputs)
-    return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= 64 and pixels >= P3_MIN_PIXELS and taps * cout >= P3_MIN_WORK
+    return P3_ENABLED and cred % 16 == 0 and cred >= 64 and cout >= P3_MIN_COUT and pixels >= P3_MIN_PIXELS and taps * cout >= P3_MIN_WORK
 
 
 def p3_of(t: torch.Tensor, lrelu_from: Optional[torch.Tensor] = None, slope: float = 0.0, colsum: Optional[list] = None) -> Optional[torch.Tensor]:
