@@ -1,6 +1,6 @@
 // How long does a wave wait between two v_mfma_f32_32x32x16_bf16 that accumulate into the SAME registers?  One wave per SIMD (as in the
 // attention backward), CHAINS independent accumulators used round-robin; cycles per MFMA from s_memtime.
-// build: hipcc --offload-arch=gfx950 -O3 experiments/mfma_chain.hip -o experiments/_mfma_chain ; run on the GPU box
+// build: hipcc --offload-arch=gfx950 -O3 tools/bench_tools/experiments/mfma_chain.hip -o tools/bench_tools/experiments/_mfma_chain ; run on the GPU box
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
