@@ -52,6 +52,7 @@ SIGNATURES = {
     "fmi_merge3_f32": [vp, vp, i64, i32, vp],
     "fmi_conv2d_fwd_f32": [PD, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "fmi_conv2d_dgrad_f32": [PD, vp, vp, vp, vp, vp, i32, i64, vp],
+    "fmi_conv_transpose2d_pair_f32": [PD, vp, vp, i32, vp, vp, vp, vp],
     "fmi_conv2d_dgrad_masked_f32": [PD, vp, vp, vp, f32, vp, vp],
     "fmi_conv2d_dgrad_masked_add_f32": [PD, vp, vp, vp, f32, vp, vp, vp],
     "fmi_conv2d_wgrad_f32": [PD, vp, vp, vp, vp, i32, i64, vp],

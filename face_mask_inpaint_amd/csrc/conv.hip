@@ -3,6 +3,7 @@
 #include "gemm_core.h"
 #include "conv3x3.h"
 #include "conv_p3.h"
+#include "convt3x3.h"
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool ep_scalar() {  // debug: FMI_EP_SCALAR = never use the 16-byte epilogue (read once)
@@ -252,6 +253,21 @@ static int dgrad_impl2(const fmi_conv_desc* d, const float* dy, const float* wt,
     }
   }
 #endif
+#ifndef FMI_HOST_EMU
+  // thin ConvTranspose2d(3, stride 2) on a large map: all four sub-pixel phases in one tap-reuse launch (convt3x3.h)
+  static const bool ct3_off = getenv("FMI_CT3_OFF") != nullptr;
+  if (!ct3_off && batch_w == 1 && !strided_split && !d->x3 && !(FMI_EXP & 32) && convt3x3_eligible(d, dy, w3)) {
+    CT3Args ca{};
+    ca.x = dy; ca.w3 = w3; ca.N = d->N; ca.H = d->OH; ca.W = d->OW; ca.Cred = d->K; ca.cs = d->y_cstride; ca.Nout = d->C;
+    ca.dW = make_fastdiv(d->OW); ca.dHW = make_fastdiv(d->OH * d->OW);
+    ConvEp ep{dx, bias, residual, d->OH, d->OW, 2, 0, 0, d->H, d->W, d->x_cstride, 0, ca.dW, ca.dHW, (int64_t)d->H * d->W * d->x_cstride};
+    ep.vec = !ep_scalar() && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(dx) && aligned16(bias) && aligned16(residual) && aligned16(mask);
+    ep.mask = mask;
+    ep.mslope = mslope;
+    ca.ep = ep;
+    return launch_convt3x3(ca, d->N * d->OH * d->OW, (hipStream_t)stream);
+  }
+#endif
   for (int py = 0; py < s; ++py) {
     for (int px = 0; px < s; ++px) {
       const int GH = (d->H - py + s - 1) / s, GW = (d->W - px + s - 1) / s;
@@ -371,6 +387,30 @@ static int dgrad_impl2(const fmi_conv_desc* d, const float* dy, const float* wt,
 extern "C" int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
                                     const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream) {
   return dgrad_impl(d, dy, wt, bias, residual, nullptr, 0.f, dx, batch_w, w_bstride, stream);
+}
+// y = ConvTranspose2d(x1, W1) + ConvTranspose2d(x2, W2) + bias for two 3x3 stride-2 transposed convolutions of the same geometry (the main
+// path and the bypass of ResBlockDecoder, base_function.py:297-305) in ONE launch of convt3x3.h: the reduction runs over x1's channels,
+// then over x2's.  d describes the first one as for fmi_conv2d_dgrad_f32 (d->K = channels of x1, d->C = output channels, d->H x d->W the
+// output, d->w3 = the piece image of its adjoint pack); K2 = channels of the dense tensor x2, w3b its piece image.
+extern "C" int fmi_conv_transpose2d_pair_f32(const fmi_conv_desc* d, const float* x1, const float* x2, int K2, const void* w3b,
+                                             const float* bias, float* y, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!x1 || !x2 || !w3b || !d->w3 || !y || K2 <= 0) return FMI_ERR_BAD_ARG;
+#ifndef FMI_HOST_EMU
+  const uint16_t* w3 = (FMI_X6 && d->K % 16 == 0 && aligned16(d->w3)) ? (const uint16_t*)d->w3 : nullptr;
+  if (!convt3x3_eligible(d, x1, w3) || (K2 & 15) || !aligned16(x2) || !aligned16(w3b) || d->pad_mode != 0 || d->x3) return FMI_ERR_UNSUPPORTED;
+  CT3Args ca{};
+  ca.x = x1; ca.w3 = w3; ca.x2 = x2; ca.w3b = (const uint16_t*)w3b; ca.Cred2 = K2; ca.cs2 = K2;
+  ca.N = d->N; ca.H = d->OH; ca.W = d->OW; ca.Cred = d->K; ca.cs = d->y_cstride; ca.Nout = d->C;
+  ca.dW = make_fastdiv(d->OW); ca.dHW = make_fastdiv(d->OH * d->OW);
+  ConvEp ep{y, bias, nullptr, d->OH, d->OW, 2, 0, 0, d->H, d->W, d->x_cstride, 0, ca.dW, ca.dHW, (int64_t)d->H * d->W * d->x_cstride};
+  ep.vec = !ep_scalar() && d->C % 4 == 0 && d->x_cstride % 4 == 0 && aligned16(y) && aligned16(bias);
+  ca.ep = ep;
+  return launch_convt3x3(ca, d->N * d->OH * d->OW, (hipStream_t)stream);
+#else
+  return FMI_ERR_UNSUPPORTED;
+#endif
 }
 extern "C" int fmi_conv2d_dgrad_masked_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* mask, float mask_slope,
                                            float* dx, void* stream) {

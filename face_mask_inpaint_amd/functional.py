@@ -743,6 +743,57 @@ class _ConvTranspose2d(torch.autograd.Function):
         return gx, gwf, gb, gres, None, None, None, None, None, None, None
 
 
+class _ConvTransposePair(torch.autograd.Function):
+    """ConvTranspose2d(x1, W1) + ConvTranspose2d(x2, W2) + bias, both kernel 3 / stride 2 / padding 1 / output_padding 1, in ONE launch
+    (fmi_conv_transpose2d_pair_f32: ResBlockDecoder's main path and bypass, base_function.py:297-305).  The backward is the two single
+    ConvTranspose2d backwards on the shared gradient."""
+
+    @staticmethod
+    def forward(ctx, x1, wf1, wt1, x2, wf2, wt2, bias, w3_1, w3_2):
+        _chk(x1, wf1, x2, wf2, bias)
+        n, h, w, cs1 = x1.shape
+        cs2, cb = x2.shape[3], wf1.shape[1]
+        H, W = 2 * h, 2 * w
+        d, oh, ow = conv_desc(n, H, W, cb, cs1, 3, 3, 2, 1, w3=w3_1[1])
+        y = torch.empty((n, H, W, cb), device=x1.device, dtype=torch.float32)
+        with _prof(f"convT_pair_fwd|{n}x{h}x{w} {cs1}+{cs2}->{cb}", 2.0 * (x1.numel() + x2.numel()) * cb * 9):
+            _L().conv_transpose2d_pair_f32(C.byref(d), _p(x1), _p(x2), cs2, C.c_void_p(w3_2[1].data_ptr()), _p(bias), _p(y), _st())
+        ctx.save_for_backward(x1, wf1, x2, wf2)
+        ctx.w3s, ctx.HW, ctx.has_bias = (w3_1, w3_2), (H, W), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import types
+
+        x1, wf1, x2, wf2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        outs = []
+        for x, wf, w3, ix, iw in ((x1, wf1, ctx.w3s[0], 0, 1), (x2, wf2, ctx.w3s[1], 3, 4)):
+            ns = types.SimpleNamespace(saved_tensors=(x, wf), cfg=(3, 3, 2, 1), has=(False, False), HW=ctx.HW, wf3=w3[0], x3=None,
+                                       needs_input_grad=(ctx.needs_input_grad[ix], ctx.needs_input_grad[iw]) + (False,) * 9)
+            outs.append(_ConvTranspose2d.backward(ns, gy)[:2])
+        gb = _bias_grad_of(gy, gy.shape[-1]) if (ctx.has_bias and ctx.needs_input_grad[6]) else None
+        return outs[0][0], outs[0][1], None, outs[1][0], outs[1][1], None, gb, None, None
+
+
+def conv_transpose2d_pair_ok(x1, pw1: PackedWeight, x2, pw2: PackedWeight) -> bool:
+    """the shapes fmi_conv_transpose2d_pair_f32 takes: fp32, thin outputs on a large map (convt3x3.h)"""
+    if x1.dtype != torch.float32 or x2.dtype != torch.float32 or not x1.is_cuda or x1.shape[:3] != x2.shape[:3]:
+        return False
+    if os.environ.get("FMI_CT3_OFF"):
+        return False
+    n, h, w, cs1 = x1.shape
+    cs2, cb = x2.shape[3], pw1.wf.shape[1]
+    return (pw1.kh == 3 and pw1.kw == 3 and pw2.kh == 3 and pw2.kw == 3 and pw2.wf.shape[1] == cb and cb <= 64 and cb % 4 == 0 and cs1 % 16 == 0 and
+            cs2 % 16 == 0 and n * h * w >= 32768 and pw1.w3[1] is not None and pw2.w3[1] is not None and x1.is_contiguous() and x2.is_contiguous() and
+            not p3_wanted(n * h * w, cs1, cb, 9))
+
+
+def conv_transpose2d_pair(x1, pw1: PackedWeight, x2, pw2: PackedWeight, bias=None):
+    return _ConvTransposePair.apply(x1, pw1.wf, pw1.wt, x2, pw2.wf, pw2.wt, bias, pw1.w3, pw2.w3)
+
+
 def conv_transpose2d(x, pw: PackedWeight, bias=None, residual=None, stride=2, pad=1, out_pad=1):
     if x.dtype == BF16:
         if bias is not None or residual is not None:

@@ -205,19 +205,26 @@ class ResBlockDecoder(_NhwcBlock):
             self._norms = (0, 3)
         self.shortcut = nn.Sequential(self.bypass)
         self._slope = _slope(nonlinearity)
+        self._pair_geometry = True  # both ConvTranspose2d are kernel 3 / stride 2 / padding 1 / output_padding 1 by construction
 
     def nhwc(self, x):
         with weight_scope(self):
+            c2, cb = _conv(self.conv2), _conv(self.bypass)
             if self._norms is None:
                 h, xp = run_conv(_conv(self.conv1), x, in_act=("apply", self._slope), passthrough=True)
-                s = run_conv(_conv(self.bypass), xp)
                 h = FF.leaky_relu(h, self._slope)
             else:
                 h, xp = _norm_act(self.model[0], x, self._slope, passthrough=True)  # the bypass ConvTranspose2d's gradient joins in the IN backward
-                s = run_conv(_conv(self.bypass), xp)
                 h = run_conv(_conv(self.conv1), h)
                 h = _norm_act(self.model[3], h, self._slope)
-            return run_conv(_conv(self.conv2), h, residual=s)
+            # main path + bypass: thin outputs on a large map go out as ONE launch (the reduction continues over the bypass input's
+            # channels: the intermediate is neither written nor re-read), otherwise the bypass result is the main convolution's residual
+            pw2, pwb = packed(c2), packed(cb)
+            if self._pair_geometry and FF.conv_transpose2d_pair_ok(h, pw2, xp, pwb):
+                bias = c2.bias if cb.bias is None else (cb.bias if c2.bias is None else FF.add(c2.bias, cb.bias))
+                return FF.conv_transpose2d_pair(h, pw2, xp, pwb, bias)
+            s = run_conv(cb, xp)
+            return run_conv(c2, h, residual=s)
 
 
 class Output(_NhwcBlock):

@@ -129,6 +129,15 @@ int fmi_conv2d_fwd_f32(const fmi_conv_desc* d, const float* x, const float* wf, 
 /* dx = conv_adjoint(dy, wt) + bias[c] + residual (dx layout = x's).  With
  * pad_mode = reflect the caller passes H,W of the PADDED input (see
  * fmi_reflect_pad_fold_f32). */
+/* y = ConvTranspose2d(x1, W1) + ConvTranspose2d(x2, W2) + bias: the main path and the bypass of ResBlockDecoder (base_function.py:297-305:
+ * two nn.ConvTranspose2d(kernel 3, stride 2, padding 1, output_padding 1) whose results are added) in one launch -- the reduction runs over
+ * x1's channels and continues over x2's, so the 1 GB intermediate is neither written nor re-read.  d describes the FIRST transposed
+ * convolution exactly as for fmi_conv2d_dgrad_f32 (d->K = channels of x1, d->C = output channels, d->H x d->W = the output, d->w3 = piece
+ * image of its adjoint pack, entry.wt3 of fmi_weight_prepare_f32); x2 is dense with K2 channels, w3b its piece image.  Thin outputs on large
+ * maps only (d->C <= 64, >= 32 768 input pixels, channels % 16 == 0); FMI_ERR_UNSUPPORTED otherwise: the caller then issues the two
+ * fmi_conv2d_dgrad_f32 calls (the second with the first's result as residual). */
+int fmi_conv_transpose2d_pair_f32(const fmi_conv_desc* d, const float* x1, const float* x2, int K2, const void* w3b, const float* bias,
+                                  float* y, void* stream);
 int fmi_conv2d_dgrad_f32(const fmi_conv_desc* d, const float* dy, const float* wt, const float* bias,
                          const float* residual, float* dx, int batch_w, int64_t w_bstride, void* stream);
 /* Adjoint of  act(x) -> conv : dx = conv_adjoint(dy, wt) * act'(x), act' = (mask > 0 ? 1 : mask_slope); mask = x or act(x), dx's layout.

@@ -243,3 +243,36 @@ def test_weight_gradient_with_pieces_of_both_operands(dev, FF, n, c, k, h, w, ks
     F.conv2d(x.permute(0, 3, 1, 2), wr, None, stride=stride, padding=pad).backward(gy.permute(0, 3, 1, 2))
     ref = wr.grad.permute(2, 3, 1, 0).reshape(ksz * ksz, c, k)
     torch.testing.assert_close(outs[1].cpu(), ref, rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cb", [(2, 128, 128, 32, 64, 32), (1, 130, 254, 64, 32, 32), (3, 96, 120, 32, 32, 64), (2, 128, 128, 16, 48, 28)])
+def test_conv_transpose_pair_equals_two_calls(dev, FF, n, h, w, c1, c2, cb):
+    """fmi_conv_transpose2d_pair_f32 (ResBlockDecoder's main path + bypass as one tap-reuse launch over all four sub-pixel phases, csrc/convt3x3.h)
+    against the two ConvTranspose2d calls it replaces (second with the first's result as residual) -- result 2e-6 of the largest entry (same
+    exact products, another summation order), gradients of both inputs, both weights and the bias 1e-5; and against torch on the CPU (1e-5).
+    Shapes: ragged rows (the last pixel of an image row is cleared for the x + 1 view), 64 output columns (two column tiles), 28 outputs."""
+    g = torch.Generator().manual_seed(n + h + c1)
+    x1 = torch.randn(n, h, w, c1, generator=g).to(dev).requires_grad_(True)
+    x2 = torch.randn(n, h, w, c2, generator=g).to(dev).requires_grad_(True)
+    w1 = (torch.randn(c1, cb, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)   # nn.ConvTranspose2d weight: [in][out][kh][kw]
+    w2 = (torch.randn(c2, cb, 3, 3, generator=g) * 0.05).to(dev).requires_grad_(True)
+    b = torch.randn(cb, generator=g).to(dev).requires_grad_(True)
+    up = torch.randn(n, 2 * h, 2 * w, cb, generator=g).to(dev)
+    res = {}
+    for pair in (True, False):
+        for t in (x1, x2, w1, w2, b):
+            t.grad = None
+        pw1, pw2 = FF.prepare_weights([(w1, None, None), (w2, None, None)])
+        if pair:
+            assert FF.conv_transpose2d_pair_ok(x1, pw1, x2, pw2)
+            y = FF.conv_transpose2d_pair(x1, pw1, x2, pw2, b)
+        else:
+            y = FF.conv_transpose2d(x1, pw1, b, residual=FF.conv_transpose2d(x2, pw2))
+        (y * up).sum().backward()
+        res[pair] = [y.detach().clone()] + [t.grad.clone() for t in (x1, x2, w1, w2, b)]
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=0, atol=2e-6 * float(res[False][0].abs().max()))
+    for a_, b_ in zip(res[True][1:], res[False][1:]):
+        torch.testing.assert_close(a_, b_, rtol=0, atol=1e-5 * float(b_.abs().max()))
+    ref = (F.conv_transpose2d(x1.detach().cpu().permute(0, 3, 1, 2), w1.detach().cpu(), None, stride=2, padding=1, output_padding=1) +
+           F.conv_transpose2d(x2.detach().cpu().permute(0, 3, 1, 2), w2.detach().cpu(), b.detach().cpu(), stride=2, padding=1, output_padding=1))
+    torch.testing.assert_close(res[True][0].cpu(), ref.permute(0, 2, 3, 1), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))

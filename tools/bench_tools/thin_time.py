@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from face_mask_inpaint_amd import functional as FF
 
 dev = torch.device("cuda:0")
+PAIR = not os.environ.get("NO_PAIR")  # NO_PAIR=1: main path and bypass as two ConvTranspose2d calls
 torch.manual_seed(0)
 n, s = 8, 512
 x = torch.randn(n, s, s, 64, device=dev, requires_grad=True)
@@ -21,8 +22,12 @@ def step():
         t.grad = None
     pw1, pw2, pwb = FF.prepare_weights([(w1, None, None), (w2, None, None, True), (wb, None, None, True)])
     h = FF.conv2d(x, pw1, b1, pad=1, in_act=("apply", 0.1))
-    sc = FF.conv_transpose2d(x, pwb, bb)
-    y = FF.conv_transpose2d(FF.leaky_relu(h, 0.1), pw2, b2, residual=sc)
+    ha = FF.leaky_relu(h, 0.1)
+    if PAIR and FF.conv_transpose2d_pair_ok(ha, pw2, x, pwb):
+        y = FF.conv_transpose2d_pair(ha, pw2, x, pwb, FF.add(b2, bb))
+    else:
+        sc = FF.conv_transpose2d(x, pwb, bb)
+        y = FF.conv_transpose2d(ha, pw2, b2, residual=sc)
     y.backward(gy)
 
 
