@@ -39,16 +39,17 @@ __device__ __forceinline__ int ct3_tap(int dy, int slot) {
 }
 
 template <int TN>
-__global__ void __launch_bounds__(256) convt3x3s2_dma_kernel(CT3Args a, int M, int tiles_n) {
+__global__ void __launch_bounds__(256, TN == 1 ? 3 : 2) convt3x3s2_dma_kernel(CT3Args a, int M, int tiles_n) {
   constexpr int BM = 128, BN = 32 * TN, BK = 16;
   constexpr int RA = ((BM + 1 + 15) / 16) * 16;  // 144 rows
   constexpr int NIA = RA / 16;                   // 9 wave instructions of an A image
   constexpr int TAPCH = 3 * 2 * BN;              // 16-byte chunks of one weight tile
   constexpr int NIB = 6 * TAPCH / 64;            // wave instructions of six weight tiles
   constexpr int NLA = (NIA + 3) / 4, NLB = (NIB + 3) / 4;
-  constexpr int ABYTES = RA * BK * 4, STAGE = ABYTES + 6 * TAPCH * 16;
-  static_assert(2 * STAGE <= 160 * 1024, "two stages in LDS");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  // stage 0 always holds a dy = 0 step (six weight tiles), stage 1 a dy = 1 step (three): 27 + 18 KB at 32 columns = three workgroups per CU
+  constexpr int ABYTES = RA * BK * 4, STAGE = ABYTES + 6 * TAPCH * 16, STAGE1 = ABYTES + 3 * TAPCH * 16;
+  static_assert(STAGE + STAGE1 <= 160 * 1024, "two stages in LDS");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGE + STAGE1];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
