@@ -160,7 +160,7 @@ SIGNATURES = {
 STATUS = {0: "ok", 1: "bad argument", 2: "unsupported shape/mode", 3: "kernel launch failed"}
 
 
-PREDICATES = {"fmi_set_deterministic": [i32], "fmi_get_deterministic": [], "fmi_conv2d_thin_supported": [PD], "fmi_conv2d_bf16_supported": [PD], "fmi_conv2d_thin_lrelu_supported": [PD]}
+PREDICATES = {"fmi_debug_bf16_tile": [i32], "fmi_set_deterministic": [i32], "fmi_get_deterministic": [], "fmi_conv2d_thin_supported": [PD], "fmi_conv2d_bf16_supported": [PD], "fmi_conv2d_thin_lrelu_supported": [PD]}
 
 
 class FmiError(RuntimeError):

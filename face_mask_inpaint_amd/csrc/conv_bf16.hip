@@ -104,14 +104,15 @@ struct ConvEpB {  // rows = anchors, written at (gy*OS+py, gx*OS+px) of the bf16
   int GH, GW, OS, py, px, OHt, OWt, cstride, Nout;
   FastDiv dGW, dG;
   int vec;
-  __device__ int64_t row_off(int row, int& n_out) const {
+  __device__ int64_t row_pix(int row, int& n_out) const {  // pixel index of the output tensor
     const uint32_t n = fdiv((uint32_t)row, dG);
     const uint32_t rem = (uint32_t)row - n * (uint32_t)(GH * GW);
     const uint32_t gy = fdiv(rem, dGW);
     const uint32_t gx = rem - gy * (uint32_t)GW;
     n_out = (int)n;
-    return ((int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px)) * cstride;
+    return (int64_t)((int)n * OHt + (int)gy * OS + py) * OWt + ((int)gx * OS + px);
   }
+  __device__ int64_t row_off(int row, int& n_out) const { return row_pix(row, n_out) * cstride; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -338,11 +339,27 @@ __global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restric
   }
 }
 
+#include "conv_bf16_8ph.h"
+
+// kernel selection override (tests / A-B timing): 0 = by shape, 1 = never the 8-wave tiles, 2 = no eight-phase kernel, 8 = the
+// eight-phase kernel wherever it is legal.  FMI_BF16_TILE in the environment sets the initial value.
+static int g_bf16_tile_mode = -1;
+static int bf16_tile_mode() {
+  if (g_bf16_tile_mode < 0) g_bf16_tile_mode = getenv("FMI_BF16_TILE") ? atoi(getenv("FMI_BF16_TILE")) : 0;
+  return g_bf16_tile_mode;
+}
+extern "C" int fmi_debug_bf16_tile(int mode) {
+  const int prev = bf16_tile_mode();
+  if (mode >= 0) g_bf16_tile_mode = mode;
+  return prev;
+}
+
 // phases: nph filled entries of set.ph (la, lb, ep, M, K); N = output channels.  ws (may be null): zeroed fp32 twin of the output
 // tensor with out_elems elements -- small feature maps with a deep reduction (the 4^2 .. 16^2 layers: 2 - 32 output tiles) then
 // split the reduction over workgroups and the sums are converted to bf16 by a second launch.
 template <int BK>
-static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws, int64_t ws_floats, int64_t out_elems, hipStream_t st) {
+static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws, int64_t ws_floats, int64_t out_elems, hipStream_t st,
+                            const EpActB* act = nullptr) {
   int Mmax = 0, Kmax = 0;
   for (int p = 0; p < nph; ++p) {
     if (set.ph[p].M > Mmax) Mmax = set.ph[p].M;
@@ -374,7 +391,34 @@ static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws,
       hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(fmi_bw_grid(out_elems / 4, 256)), dim3(256), 0, st, ws, y, out_elems / 4);      \
   } while (0)
   auto wgs = [&](int bm, int bn) { return ceil_div64(Mmax, bm) * ceil_div64(N, bn) * nph; };
-  static const int tile_dbg = getenv("FMI_BF16_TILE") ? atoi(getenv("FMI_BF16_TILE")) : 0;  // debug: 1 = never use the 8-wave tiles
+  const int tile_dbg = bf16_tile_mode();
+  // the eight-phase kernel (conv_bf16_8ph.h): whole 64-deep reduction tiles, 8-byte output stores, no split reduction
+  bool ok8 = BK == 64 && tile_dbg != 1 && tile_dbg != 2 && N % 4 == 0 && N > 64;
+  for (int p = 0; p < nph && ok8; ++p)
+    ok8 = set.ph[p].K % 64 == 0 && set.ph[p].ep.vec && (!set.ph[p].ep.colscale || (((uintptr_t)set.ph[p].ep.colscale & 15) == 0));
+  if (act && act->on && !ok8) return FMI_ERR_UNSUPPORTED;
+  if (ok8) {
+    const bool wide = N > 128;
+    const int64_t w8 = wide ? wgs(256, 256) : wgs(512, 128);
+    if (tile_dbg == 8 || (act && act->on) || w8 >= 200) {
+      const int64_t tn = ceil_div64(N, wide ? 256 : 128);
+      int64_t tmax = 0;
+      for (int p = 0; p < nph; ++p) {
+        const int64_t t = ceil_div64(set.ph[p].M, wide ? 256 : 512) * tn;
+        if (t > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+        set.ph[p].tiles = (int)t;
+        if (t > tmax) tmax = t;
+      }
+      set.tiles_n = (int)tn;
+      set.ksplit = 1;
+      set.ws = nullptr;
+      EpActB a{};
+      if (act) a = *act;
+      if (wide) hipLaunchKernelGGL((conv_bf16_8ph_kernel<T8P256x256>), dim3((unsigned)tmax, nph, 1), dim3(512), 0, st, set, a);
+      else hipLaunchKernelGGL((conv_bf16_8ph_kernel<T8P512x128>), dim3((unsigned)tmax, nph, 1), dim3(512), 0, st, set, a);
+      return fmi_launch_status();
+    }
+  }
   if (N <= 32) {
     FMI_LAUNCH_B(TB128x32);
   } else if (N <= 64) {

@@ -1,0 +1,278 @@
+// bf16 implicit-GEMM convolution, forward / adjoint, for the decoder's large layers: eight waves, every wave 128 pixels x 64 output
+// channels of fp32 accumulators (128 registers), reduction tile 64, v_mfma_f32_16x16x32_bf16, the whole LDS as a two-tile ring
+// that is filled in HALF-IMAGES several phases ahead of its use.  Included by conv_bf16.hip (loaders ConvKB / ConvWKB / ConvEpB).
+//
+// Schedule ("phases"; stylegan2/model.py:241-279 is what the launches compute, the schedule is this file's own):
+//  * a reduction tile is four phases, one per 64 x 32 quadrant of the wave's accumulators: (i0,j0) (i0,j1) (i1,j1) (i1,j0) -- a Gray
+//    path, each step replaces ONE operand: phase 0 reads the pixel half i0 (8 ds_read_b128) and the channel half j0 (4), phase 1 j1
+//    (4), phase 2 i1 (8), phase 3 nothing; 16 MFMAs per phase.
+//  * the LDS images are cut by WHEN they are read, not by which wave reads them: A0 = the i0 rows of every wave (read in phase 0
+//    only), B0 = the j0 columns (phase 0), B1 = j1 (phase 1), A1 = i1 (phase 2).  Every half-image therefore has ONE reading phase,
+//    and it can be refilled two phases later: phase 4u+0 fills B1 of tile u+1, 4u+1 A1 of u+1, 4u+2 A0 of u+2, 4u+3 B0 of u+2 --
+//    each at least five phases before its read, four half-images (2 NA + 2 NB LDS-DMA instructions per thread) in flight behind
+//    every counted s_waitcnt vmcnt, never vmcnt(0) inside the loop.
+//  * two barriers per phase and the second four waves one barrier behind the first four: a SIMD's two waves alternate between
+//    "LDS reads + DMA issue" and "16 MFMAs", so the matrix pipe of every SIMD always has one wave in its MFMA section.
+//  * ordering: a half-image is waited for (each wave its own DMA instructions) in the phase BEFORE the one that reads it, so a
+//    barrier lies between any wave's wait and any wave's read -- also across the one-barrier stagger; a half-image is refilled
+//    at least two phases after its reading phase, so every wave's lgkmcnt(0) of those reads lies before the refill is issued.
+//  * source-side swizzle (the DMA writes lane-linear): chunk column ^ ((row >> 1) & 7); the 16-lane groups of a ds_read_b128 of the
+//    16x16x32 operand layout (rows l & 15, chunk l >> 4) then cover the 64 banks once.
+//  * operands are passed (weights, pixels), so a lane's four accumulator registers are four consecutive CHANNELS of one pixel
+//    (D row = 4 (l >> 4) + r, column = l & 15): 8-byte bf16 stores.
+#pragma once
+
+template <int WM_, int WN_>
+struct Tile8P {
+  static constexpr int WM = WM_, WN = WN_, BM = WM * 128, BN = WN * 64, NT = 512;
+  static constexpr int NA = BM / 128, NB = BN / 128;                // LDS-DMA instructions per thread and half-image
+  static constexpr int AH = BM / 2 * 128, BH = BN / 2 * 128;        // bytes of a half-image ([rows][64 bf16])
+  static constexpr int STAGE = 2 * AH + 2 * BH;                     // A0 | A1 | B0 | B1
+  static_assert(WM * WN == 8 && NB >= 1, "eight waves");
+};
+using T8P256x256 = Tile8P<2, 4>;
+using T8P512x128 = Tile8P<4, 2>;  // the 128-channel layers; 2 x 80 KB = the whole LDS
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// fused output stage of a StyledConv (stylegan2/model.py:250-252 demodulation, :305-311 NoiseInjection, op/fused_act.py:30-37
+// FusedLeakyReLU): y = lrelu(acc * colscale[n][c] + nw * noise[n][oy][ox] + bias[c]) * gain
+struct EpActB {
+  const float* noise;  // [N][OH][OW] or null
+  const float* nw;     // one float (device)
+  const float* bias;   // [Nout] or null
+  float slope, gain;
+  int on;
+};
+
+template <class T>
+__global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB act) {
+  constexpr int BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, AH = T::AH, BH = T::BH, STAGE = T::STAGE;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  if (lid >= set.ph[blockIdx.y].tiles) return;  // whole workgroup
+  const ConvKB la = set.ph[blockIdx.y].la;
+  const ConvWKB lb = set.ph[blockIdx.y].lb;
+  const int K = set.ph[blockIdx.y].K, tiles_n = set.tiles_n;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / T::WN, wc = wid % T::WN, grp = wid >> 2;
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- staging contexts: thread tid fills chunk position tid & 7 of local rows (tid >> 3) + 64 j of every half-image
+  const int r0 = tid >> 3, kq = (((tid & 7) ^ ((tid >> 4) & 7)) << 3);
+  ConvKB::DCtx da[2][NA];
+  ConvWKB::DCtx db[2][NB];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) da[sub][j] = la.dprep(m0 + j * 128 + sub * 64 + r0, kq);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int lr = r0 + 64 * j;
+      db[sub][j] = lb.dprep(n0 + (lr >> 5) * 64 + sub * 32 + (lr & 31), kq);
+    }
+  }
+
+  // the zero chunk's address is read from the GOT: once, and pinned in scalar registers (re-read inside the loop it put an
+  // s_waitcnt lgkmcnt(0) -- which also waits for every LDS read in flight -- in front of each DMA issue)
+  const void* zp = fmi_chunk_zero;
+  asm volatile("" : "+s"(zp));
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto glds16 = [&](const void* g, uint32_t dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(dst)
+                 : "memory");
+  };
+  auto issueA = [&](int sub, int tile, int st) {
+    const ConvKB::Tile ta = la.tile(tile * 64);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + sub * AH) + (uint32_t)wid * 1024u);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const ConvKB::DCtx& d = da[sub][j];
+      const bool ok = (unsigned)(d.ry + ta.dy) < (unsigned)la.g.IH && (unsigned)(d.rx + ta.dx) < (unsigned)la.g.IW;
+      const void* g = ok ? (const void*)(la.p + d.boff + ta.uoff) : zp;
+      glds16(g, dst + j * 8192);
+    }
+  };
+  auto issueB = [&](int sub, int tile, int st) {
+    const ConvWKB::Tile tb = lb.tile(tile * 64);
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(st * STAGE + 2 * AH + sub * BH) + (uint32_t)wid * 1024u);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const void* g = db[sub][j].off >= 0 ? (const void*)(lb.p + db[sub][j].off + tb.toff) : zp;
+      glds16(g, dst + j * 8192);
+    }
+  };
+  auto wait_copies = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+
+  // ---- fragment read addresses (bytes from the start of a stage)
+  const int l15 = lane & 15, c0 = (lane >> 4) ^ ((lane >> 1) & 7);
+  const uint32_t a_off0 = (uint32_t)(wr * 8192 + l15 * 128 + c0 * 16), a_off1 = a_off0 ^ 64u;
+  const uint32_t b_off0 = (uint32_t)(2 * AH + wc * 4096 + l15 * 128 + c0 * 16), b_off1 = b_off0 ^ 64u;
+
+  f32x4v acc[2][2][4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[i][j][r][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ax[4][2], bw0[2][2], bw1[2][2];
+
+  const int nt = K >> 6;  // reduction tiles (K % 64 == 0 is the host's condition for this kernel)
+  auto read_a = [&](int st, int sub) {
+    const unsigned char* p0 = lds + st * STAGE + sub * AH + a_off0;
+    const unsigned char* p1 = lds + st * STAGE + sub * AH + a_off1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ax[r][0] = *reinterpret_cast<const bf16x8*>(p0 + r * 2048);
+      ax[r][1] = *reinterpret_cast<const bf16x8*>(p1 + r * 2048);
+    }
+  };
+  auto read_b = [&](int st, int sub, bf16x8 (&bw)[2][2]) {
+    const unsigned char* p0 = lds + st * STAGE + sub * BH + b_off0;
+    const unsigned char* p1 = lds + st * STAGE + sub * BH + b_off1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bw[c][0] = *reinterpret_cast<const bf16x8*>(p0 + c * 2048);
+      bw[c][1] = *reinterpret_cast<const bf16x8*>(p1 + c * 2048);
+    }
+  };
+  auto mfmas = [&](f32x4v (&d)[4][2], const bf16x8 (&bw)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) d[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[c][s], ax[r][s], d[r][c], 0, 0, 0);
+  };
+#define FMI_8P_MID()                                  \
+  __builtin_amdgcn_s_barrier();                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0);                  \
+  __builtin_amdgcn_s_setprio(1)
+#define FMI_8P_END()                 \
+  __builtin_amdgcn_s_setprio(0);     \
+  __builtin_amdgcn_sched_barrier(0); \
+  __builtin_amdgcn_s_barrier();      \
+  asm volatile("" ::: "memory")
+
+  if (nt > 0) {
+    // prologue: tile 0 whole, A0 / B0 of tile 1 -- the order the loop issues in
+    issueA(0, 0, 0);
+    issueB(0, 0, 0);
+    issueB(1, 0, 0);
+    issueA(1, 0, 0);
+    if (nt > 1) {
+      issueA(0, 1, 1);
+      issueB(0, 1, 1);
+    }
+    wait_copies(NA + NB + (nt > 1 ? NA + NB : 0));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp) __builtin_amdgcn_s_barrier();  // the second four waves run one barrier behind
+    int st = 0;
+    for (int u = 0; u < nt; ++u) {
+      const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
+      // phase 0: quadrant (i0, j0)
+      read_b(st, 0, bw0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(st, 0);
+      if (n1) issueB(1, u + 1, st ^ 1);
+      wait_copies(NA + (n1 ? NA + 2 * NB : 0));
+      FMI_8P_MID();
+      mfmas(acc[0][0], bw0);
+      FMI_8P_END();
+      // phase 1: (i0, j1)
+      read_b(st, 1, bw1);
+      if (n1) issueA(1, u + 1, st ^ 1);
+      wait_copies(n1 ? 2 * NA + 2 * NB : 0);
+      FMI_8P_MID();
+      mfmas(acc[0][1], bw1);
+      FMI_8P_END();
+      // phase 2: (i1, j1)
+      read_a(st, 1);
+      if (n2) issueA(0, u + 2, st);
+      FMI_8P_MID();
+      mfmas(acc[1][1], bw1);
+      FMI_8P_END();
+      // phase 3: (i1, j0)
+      if (n2) issueB(0, u + 2, st);
+      wait_copies((n1 ? NA + NB : 0) + (n2 ? NA + NB : 0));
+      FMI_8P_MID();
+      mfmas(acc[1][0], bw0);
+      FMI_8P_END();
+      st ^= 1;
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
+  }
+#undef FMI_8P_MID
+#undef FMI_8P_END
+
+  // ---- output: lane = pixel (l & 15) of each 16-pixel group, four consecutive channels 4 (l >> 4) .. + 3 of each 16-channel group
+  const ConvEpB ep = set.ph[blockIdx.y].ep;
+  const int M = set.ph[blockIdx.y].M, N = set.N;
+  const int cl = 4 * (lane >> 4);
+  const float nwv = (act.on && act.noise) ? act.nw[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wr * 128 + i * 64 + r * 16 + l15;
+      if (row >= M) continue;
+      int n_s = 0;
+      const int64_t pix = ep.row_pix(row, n_s), off = pix * ep.cstride;
+      float nz = 0.f;
+      if (act.on && act.noise) nz = nwv * act.noise[pix];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int col = n0 + wc * 64 + j * 32 + c * 16 + cl;
+          if (col >= N) continue;
+          float a[4] = {acc[i][j][r][c][0], acc[i][j][r][c][1], acc[i][j][r][c][2], acc[i][j][r][c][3]};
+          if (ep.colscale) {
+            const float4 cs = *reinterpret_cast<const float4*>(ep.colscale + (int64_t)n_s * ep.Nout + col);
+            a[0] *= cs.x, a[1] *= cs.y, a[2] *= cs.z, a[3] *= cs.w;
+          }
+          if (act.on) {
+            float4 b = {0.f, 0.f, 0.f, 0.f};
+            if (act.bias) b = *reinterpret_cast<const float4*>(act.bias + col);
+            const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = a[e] + nz + bb[e];
+              a[e] = (v < 0.f ? v * act.slope : v) * act.gain;
+            }
+          }
+          uint2 v;
+          v.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+          v.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+          *reinterpret_cast<uint2*>(ep.y + off + col) = v;
+        }
+      }
+    }
+  }
+}

@@ -48,6 +48,11 @@ int fmi_version(void);
 int fmi_set_deterministic(int on);
 int fmi_get_deterministic(void);
 
+/* Kernel selection override of the bf16 convolution family (tests and A/B timing; initial value from FMI_BF16_TILE): 0 = by shape,
+ * 1 = never the eight-wave tiles, 2 = no eight-phase kernel, 8 = the eight-phase kernel (csrc/conv_bf16_8ph.h) wherever it is legal.
+ * mode < 0 only queries.  Returns the previous mode. */
+int fmi_debug_bf16_tile(int mode);
+
 /* ------------------------------------------------------------------------
  * Dense batched GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
  *   C[b] = alpha * A[b] . B[b] (+ bias[n]) + beta * C[b]

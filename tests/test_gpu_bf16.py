@@ -112,6 +112,52 @@ def test_conv_bf16_split_reduction(dev, FF, n, c, k, h, stride):
     close_bf16(dx, xr.grad.permute(0, 2, 3, 1))
 
 
+# (n, c, k, h, w, ks, stride, pad): shapes that reach the eight-phase kernel (csrc/conv_bf16_8ph.h) when it is forced: both tiles
+# (256 x 256 for more than 128 output channels, 512 x 128 below), ragged pixel / channel tiles, one to eighteen reduction tiles (the
+# prologue, the steady state and the drained tail of the DMA ring), the four sub-pixel phases of a stride-2 adjoint with 1 / 2 / 2 / 4 taps
+EIGHT_PHASE_CASES = [(3, 128, 256, 32, 32, 3, 1, 1), (2, 64, 128, 24, 20, 3, 1, 1), (2, 64, 320, 9, 11, 3, 1, 1), (1, 64, 128, 16, 16, 1, 1, 0),
+                     (2, 128, 128, 17, 13, 3, 2, 0), (2, 256, 192, 12, 12, 3, 2, 0), (1, 128, 64, 40, 40, 3, 1, 1), (5, 192, 256, 8, 8, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ks,stride,pad", EIGHT_PHASE_CASES)
+def test_conv_bf16_eight_phase_kernel(dev, FF, n, c, k, h, w, ks, stride, pad):
+    """forward (+ demodulation column scale) and adjoint through the eight-phase kernel, against torch on the same bf16 operands,
+    and bit for bit against the default kernels' results where those accumulate in the same order class (same tolerance otherwise)"""
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(c + k + h)
+    x = bf(torch.randn(n, c, h, w, generator=g))
+    wt_ = bf(torch.randn(k, c, ks, ks, generator=g) / (c * ks * ks) ** 0.5)
+    xr, wr = x.float().requires_grad_(True), wt_.float().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    gy = bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy.float())
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ks, ks, stride, pad, 0)
+    wnk = FF._pack_bf16(wt_.float().permute(2, 3, 1, 0).reshape(ks * ks, c, k).contiguous().to(dev))
+    wck = FF._pack_bf16(wt_.float().permute(2, 3, 0, 1).reshape(ks * ks, k, c).contiguous().to(dev))
+    xh, gh = x.permute(0, 2, 3, 1).contiguous().to(dev), gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    st = FF._st()
+    cs = (torch.rand(n, k, generator=g) + 0.5).to(dev)
+    prev = lib.debug_bf16_tile(8)
+    try:
+        y = torch.full((n, oh, ow, k), float("nan"), dtype=BF, device=dev)
+        lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), None, FF._p(y), None, 0, st)
+        close_bf16(y, y_ref.detach().permute(0, 2, 3, 1))
+        lib.conv2d_fwd_bf16(C.byref(d), FF._p(xh), FF._p(wnk), FF._p(cs), FF._p(y), None, 0, st)
+        close_bf16(y, y_ref.detach().permute(0, 2, 3, 1) * cs.cpu().view(n, 1, 1, k))
+        dx = torch.full((n, h, w, c), float("nan"), dtype=BF, device=dev)
+        lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx), None, 0, st)
+        close_bf16(dx, xr.grad.permute(0, 2, 3, 1))
+        # repeated launches: the counted waits / barrier placement leave no run-to-run difference
+        dx2 = torch.empty_like(dx)
+        for _ in range(3):
+            lib.conv2d_dgrad_bf16(C.byref(d), FF._p(gh), FF._p(wck), None, FF._p(dx2), None, 0, st)
+            assert torch.equal(dx, dx2)
+    finally:
+        lib.debug_bf16_tile(prev)
+
+
 def test_conv_bf16_rejects_unsupported(dev, FF):
     from face_mask_inpaint_amd import _lib
 
