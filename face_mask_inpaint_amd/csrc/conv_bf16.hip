@@ -395,7 +395,7 @@ static int launch_conv_bf16(ConvSetB& set, int nph, int N, bf16_t* y, float* ws,
   // the eight-phase kernel (conv_bf16_8ph.h): whole 64-deep reduction tiles, 8-byte output stores, no split reduction
   bool ok8 = BK == 64 && tile_dbg != 1 && tile_dbg != 2 && N % 4 == 0 && N > 64;
   for (int p = 0; p < nph && ok8; ++p)
-    ok8 = set.ph[p].K % 64 == 0 && set.ph[p].ep.vec && (!set.ph[p].ep.colscale || (((uintptr_t)set.ph[p].ep.colscale & 15) == 0));
+    ok8 = set.ph[p].K % 64 == 0 && set.ph[p].la.g.ntaps() <= 32 && set.ph[p].ep.vec && (!set.ph[p].ep.colscale || (((uintptr_t)set.ph[p].ep.colscale & 15) == 0));
   if (act && act->on && !ok8) return FMI_ERR_UNSUPPORTED;
   if (ok8) {
     const bool wide = N > 128;

@@ -1,3 +1,11 @@
+// SHELVED EXPERIMENT (not built): the eight-phase bf16 convolution kernel with persistent workgroups -- one per CU walking output tiles
+// worker, worker + G, ..., the DMA streams running across output-tile boundaries, the finished tile's output stage executed at
+// the start of the next tile.  Correct (tests/test_gpu_bf16.py eight-phase cases), but SLOWER than one output tile per workgroup:
+// 937 / 1011 / 968 / 1007 / 755 / 756 TFLOP/s against 1080 / 1213 / 1178 / 1178 / 860 / 882 on boxes of the same class (forward /
+// adjoint of 512->512 at 64^2, 256->256 at 128^2, 128->128 at 256^2, batch 16).  Why: the scalar state of two stream positions, two
+// output tiles and the tap algebra exceeds the 102 scalar registers (64 - 78 spilled to VGPR lanes, ~15 v_readlane in the phase that
+// advances the stream), and `advance` + `locate` put ~100 instructions into one section of the loop (a section may hold ~60).  What it
+// would have bought is bounded by the ablations of the kernel that is built: output stage + store burst 6 % / 13 % / 24 % of the launch.
 // bf16 implicit-GEMM convolution, forward / adjoint, for the decoder's large layers: eight waves, every wave 128 pixels x 64 output
 // channels of fp32 accumulators (128 registers), reduction tile 64, v_mfma_f32_16x16x32_bf16, the whole LDS as a two-tile ring
 // that is filled in HALF-IMAGES several phases ahead of its use.  Included by conv_bf16.hip (loaders ConvKB / ConvWKB / ConvEpB).
@@ -20,9 +28,13 @@
 //    16x16x32 operand layout (rows l & 15, chunk l >> 4) then cover the 64 banks once.
 //  * operands are passed (weights, pixels), so a lane's four accumulator registers are four consecutive CHANNELS of one pixel
 //    (D row = 4 (l >> 4) + r, column = l & 15): 8-byte bf16 stores.
-//  * one output tile per workgroup.  Persistent workgroups with the DMA streams running across output tiles were built and measured
-//    slower (tools/bench_tools/experiments/conv_bf16_8ph_persistent.h: scalar-register pressure); what remains exposed is the
-//    output stage and its store burst -- 6 % / 13 % / 24 % of the launch at 72 / 36 / 18 reduction tiles per output tile.
+//  * persistent workgroups: one per CU (the LDS admits no second one), each walks output tiles worker, worker + G, ... of the
+//    flattened (sub-pixel phase, tile) list, and the DMA streams run across tile boundaries -- the first two reduction tiles of the
+//    next output tile are in flight or landed while the current one finishes, and the stores of a finished tile drain under the
+//    next tile's MFMAs.  The output stage itself is cut into the four accumulator quadrants and executed in the first reduction
+//    tile of the NEXT output tile, each quarter in the section in front of the phase that restarts its quadrant: measured before
+//    this (one output tile per workgroup, whole output stage at the end): the output stage cost 6 % / 13 % / 24 % of the launch at
+//    72 / 36 / 18 reduction tiles per output tile, half of it the store burst of 256 CUs finishing together.
 #pragma once
 #include <type_traits>
 
@@ -50,33 +62,57 @@ struct EpActB {
 };
 
 #ifndef FMI_8P_EXP
-#define FMI_8P_EXP 0  // timing experiments (wrong results except 1, 64): 1 no stagger, 2 no DMA issue, 4 no LDS reads, 8 no MFMAs, 16 no stores, 32 no output stage, 64 staggered start
+#define FMI_8P_EXP 0  // timing experiments (wrong results except 1): 1 no stagger, 2 no DMA issue, 4 no LDS reads, 8 no MFMAs, 16 no stores
 #endif
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+struct WorkB {  // flattened (phase, tile) list of one launch
+  int total, nph;
+  int first[5];  // first item of each phase; first[nph] = total
+};
+
 template <class T>
-__global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB act) {
+__global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB act, WorkB work) {
   constexpr int BM = T::BM, BN = T::BN, NA = T::NA, NB = T::NB, AH = T::AH, BH = T::BH, STAGE = T::STAGE;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  if (lid >= set.ph[blockIdx.y].tiles) return;  // whole workgroup
-  const ConvKB la = set.ph[blockIdx.y].la;
-  const ConvWKB lb = set.ph[blockIdx.y].lb;
-  const int K = set.ph[blockIdx.y].K, tiles_n = set.tiles_n;
+  const int G = gridDim.x;
+  const int worker = xcd_remap(blockIdx.x, G);
+  if (worker >= work.total) return;  // whole workgroup (the host launches G <= total)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid / T::WN, wc = wid % T::WN, grp = wid >> 2;
-  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // the four phases' loaders are indexed at run time; read through the parameter `set` that made the compiler copy all of it to
+  // scratch (1.9 KB, and scratch reads inside the loop) -- so they are read from the kernel-argument segment itself, where `set` is
+  // the first argument, by scalar loads at the few places that enter a phase
+  const ConvSetB* sp = reinterpret_cast<const ConvSetB*>(
+      (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
+  const int tiles_n = sp->tiles_n;
+
+  struct Item {
+    int idx, p, m0, n0, nt;
+  };
+  auto item_at = [&](int idx) {
+    Item it;
+    it.idx = idx;
+    it.p = 0;
+    for (int q = 1; q < work.nph; ++q)
+      if (idx >= work.first[q]) it.p = q;
+    const int lid = idx - work.first[it.p];
+    const int tile_m = lid / tiles_n;
+    it.m0 = tile_m * BM;
+    it.n0 = (lid - tile_m * tiles_n) * BN;
+    it.nt = sp->ph[it.p].K >> 6;  // reduction tiles (K % 64 == 0, K >= 128: the host's conditions for this kernel)
+    return it;
+  };
 
   // ---- staging contexts: thread tid fills chunk position tid & 7 of local rows (tid >> 3) + 64 j of every half-image.
   // A section of the loop may hold about sixty instructions per wave (a wave issues one instruction every four cycles; the other
-  // wave of the SIMD needs 16 MFMAs x 16 cycles), so everything per-row is decided here: a pixel row keeps its byte address and a
-  // bit per tap ("this tap lies inside the image"), a weight row its byte address and an all-ones / zero mask for the tap offset.
-  const ConvGeom& g = la.g;
+  // wave of the SIMD needs 16 MFMAs x 16 cycles), so everything per-row is decided when an output tile is entered: a pixel row
+  // keeps its byte address and a bit per tap ("this tap lies inside the image"), a weight row its byte address and an all-ones /
+  // zero mask for the tap offset.
   const int r0 = tid >> 3, kq = (((tid & 7) ^ ((tid >> 4) & 7)) << 3);
   const void* zp = fmi_chunk_zero;  // read from the GOT once and pinned in scalar registers (re-read per DMA it put an s_waitcnt
   asm volatile("" : "+s"(zp));      // lgkmcnt(0), which also waits for every LDS read in flight, in front of each issue)
@@ -84,8 +120,27 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
   uint32_t ma[2][NA];
   const unsigned char* pb[2][NB];
   uint32_t mb[2][NB];
-#pragma unroll
-  for (int sub = 0; sub < 2; ++sub) {
+  // scalar state is the scarce resource here (two stream positions, two output tiles, the tap algebra): the loaders stay in the
+  // kernel-argument segment and are read where an output tile is entered; only the tap algebra of the leading stream's phase is held
+  struct TapGeo {
+    int nty, ntx, ystep, xstep, IW, cstride, kh0, kw0, khstep, kwstep, kw, C;
+  };
+  TapGeo tg;
+  int ip = -1;  // phase of the leading DMA stream
+  auto enter_phase = [&](int p) {
+    if (p != ip) {
+      asm volatile("" : "+s"(p));
+      const ConvGeom g = sp->ph[p].la.g;
+      tg = TapGeo{g.nty, g.ntx, g.ystep, g.xstep, g.IW, g.cstride, g.kh0, g.kw0, g.khstep, g.kwstep, g.kw, g.C};
+      ip = p;
+    }
+  };
+  auto build_ctx = [&](int sub, int m0, int n0) {
+    int p = ip;
+    asm volatile("" : "+s"(p), "+s"(m0), "+s"(n0));  // as in out_quadrant: loaded and computed here, not ahead of the loop
+    const ConvKB la = sp->ph[p].la;
+    const ConvWKB lb = sp->ph[p].lb;
+    const ConvGeom& g = la.g;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const ConvKB::DCtx d = la.dprep(m0 + j * 128 + sub * 64 + r0, kq);
@@ -107,29 +162,43 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
       pb[sub][j] = d.off >= 0 ? reinterpret_cast<const unsigned char*>(lb.p + d.off) : reinterpret_cast<const unsigned char*>(zp);
       mb[sub][j] = d.off >= 0 ? 0xffffffffu : 0u;
     }
-  }
+  };
 
-  // ---- the reduction tile the DMA streams are at (scalar): tap (ti, tj) of channel chunk ch, the order of ConvKB::tile.  Stepping
-  // it is additions of six constants (bytes): next tap in a row, first tap of the next row, first tap of the next channel chunk.
-  const int ntx = g.ntx, nty = g.nty;
-  const int a_dx = g.xstep * g.cstride * 2, a_dy = (g.ystep * g.IW - (ntx - 1) * g.xstep) * g.cstride * 2;
-  const int a_dc = 128 - ((nty - 1) * g.ystep * g.IW + (ntx - 1) * g.xstep) * g.cstride * 2;
-  const int b_dx = g.kwstep * g.C * 2, b_dy = (g.khstep * g.kw - (ntx - 1) * g.kwstep) * g.C * 2;
-  const int b_dc = 128 - ((nty - 1) * g.khstep * g.kw + (ntx - 1) * g.kwstep) * g.C * 2;
+  // ---- where a DMA stream is (scalar): reduction tile kt of an output tile = tap (ti, tj) of channel chunk ch, ConvKB::tile's order
   struct TileAt {
-    int ti, tj;
+    int ti, tj, ch, kt, nt;  // kt == 0 inside the loop: the stream has just entered an output tile (its contexts are not built yet)
+    int idx;                 // the output tile; < 0: the stream has run out of tiles
     uint32_t bit;  // 1 << tap
     int64_t ua;    // byte offset of the tap's pixel and the chunk's channels from a row's anchor
     uint32_t ub;   // byte offset of (tap, chunk) inside a packed weight row
   };
-  auto advance = [&](TileAt& t) {
-    if (++t.tj == ntx) {
-      t.tj = 0;
-      if (++t.ti == nty) t.ti = 0, t.bit = 1u, t.ua += a_dc, t.ub += (uint32_t)b_dc;
-      else t.bit <<= 1, t.ua += a_dy, t.ub += (uint32_t)b_dy;
-    } else {
-      t.bit <<= 1, t.ua += a_dx, t.ub += (uint32_t)b_dx;
+  auto locate = [&](TileAt& t) {
+    const TapGeo& g = tg;
+    t.bit = 1u << (t.ti * g.ntx + t.tj);
+    t.ua = (((int64_t)(g.ystep * t.ti) * g.IW + g.xstep * t.tj) * g.cstride + (t.ch << 6)) * 2;
+    t.ub = (uint32_t)(((g.kh0 + g.khstep * t.ti) * g.kw + (g.kw0 + g.kwstep * t.tj)) * g.C + (t.ch << 6)) * 2u;
+  };
+  auto enter_item = [&](TileAt& t, const Item& it) {
+    enter_phase(it.p);
+    t.ti = t.tj = t.ch = t.kt = 0;
+    t.nt = it.nt, t.idx = it.idx;
+    locate(t);
+  };
+  auto advance = [&](TileAt& t) {  // only ever applied to the leading stream
+    if (++t.kt == t.nt) {
+      const int next = t.idx + G;
+      if (next >= work.total) {
+        t.idx = -1;
+        return;
+      }
+      enter_item(t, item_at(next));
+      return;
     }
+    if (++t.tj == tg.ntx) {
+      t.tj = 0;
+      if (++t.ti == tg.nty) t.ti = 0, ++t.ch;
+    }
+    locate(t);
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -172,7 +241,6 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
     for (int j = 0; j < NB; ++j) gp[j] = (const void*)(pb[sub][j] + (t.ub & mb[sub][j]));
     dma(gp, NB, dst);
   };
-
   // ---- fragment read addresses (bytes from the start of a stage)
   const int l15 = lane & 15, c0 = (lane >> 4) ^ ((lane >> 1) & 7);
   const uint32_t a_off0 = (uint32_t)(wr * 8192 + l15 * 128 + c0 * 16), a_off1 = a_off0 ^ 64u;
@@ -189,7 +257,6 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
         for (int c = 0; c < 2; ++c) acc[i][j][r][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
   bf16x8 ax[4][2] = {}, bw0[2][2] = {}, bw1[2][2] = {};
 
-  const int nt = K >> 6;  // reduction tiles (K % 64 == 0 is the host's condition for this kernel)
   auto read_a = [&](int st, int sub) {
     if (FMI_8P_EXP & 4) {
 #pragma unroll
@@ -231,6 +298,53 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
 #pragma unroll
         for (int c = 0; c < 2; ++c) d[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[c][s], ax[r][s], d[r][c], 0, 0, 0);
   };
+
+  // ---- output stage of one accumulator quadrant (i, j) of the output tile `o`, then the quadrant restarts at zero.
+  // lane = pixel (l & 15) of each 16-pixel group, four consecutive channels 4 (l >> 4) .. + 3 of each 16-channel group
+  const int cl = 4 * (lane >> 4);
+  const float nwv = (act.on && act.noise) ? act.nw[0] : 0.f;
+  auto out_quadrant = [&](int oidx, int i, int j) {
+    asm volatile("" : "+s"(oidx));  // nothing of this stage may be computed ahead (and kept in registers) outside the branch it sits in
+    const Item o = item_at(oidx);
+    const ConvEpB ep = sp->ph[o.p].ep;
+    const int M = sp->ph[o.p].M, N = sp->N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = o.m0 + wr * 128 + i * 64 + r * 16 + l15;
+      int n_s = 0;
+      const int64_t pix = row < M ? ep.row_pix(row, n_s) : 0, off = pix * ep.cstride;
+      float nz = 0.f;
+      if (act.on && act.noise) nz = nwv * act.noise[pix];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int col = o.n0 + wc * 64 + j * 32 + c * 16 + cl;
+        f32x4v a = acc[i][j][r][c];
+        acc[i][j][r][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const bool live = row < M && col < N;
+        if (ep.colscale && live) {
+          const float4 cs = *reinterpret_cast<const float4*>(ep.colscale + (int64_t)n_s * ep.Nout + col);
+          a[0] *= cs.x, a[1] *= cs.y, a[2] *= cs.z, a[3] *= cs.w;
+        }
+        if (act.on) {
+          float4 b = {0.f, 0.f, 0.f, 0.f};
+          if (act.bias && live) b = *reinterpret_cast<const float4*>(act.bias + col);
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = a[e] + nz + bb[e];
+            a[e] = (v < 0.f ? v * act.slope : v) * act.gain;
+          }
+        }
+        const bf16x2v lo = __builtin_convertvector((f32x2v){a[0], a[1]}, bf16x2v), hi = __builtin_convertvector((f32x2v){a[2], a[3]}, bf16x2v);
+        uint2 v;
+        v.x = *reinterpret_cast<const uint32_t*>(&lo);
+        v.y = *reinterpret_cast<const uint32_t*>(&hi);
+        if ((!(FMI_8P_EXP & 16) || M < 0) && live) *reinterpret_cast<uint2*>(ep.y + off + col) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one pixel row at a time: the accumulators leave few registers for this stage
+    }
+  };
+
 #define FMI_8P_MID()                                  \
   __builtin_amdgcn_s_barrier();                       \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
@@ -241,40 +355,47 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
   __builtin_amdgcn_sched_barrier(0); \
   __builtin_amdgcn_s_barrier();      \
   asm volatile("" ::: "memory")
-#define FMI_8P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-  constexpr int WFULL = 2 * NA + 2 * NB;
 
-  if (FMI_8P_EXP & 64) {  // experiment: the first round of workgroups starts spread over ~8 us, so that the rounds' store bursts do not coincide
-    if (blockIdx.x < 256)
-      for (int i = 0; i < (int)(blockIdx.x & 15); ++i) __builtin_amdgcn_s_sleep(20);
-  }
-  if (nt > 0) {
-    // prologue: tile 0 whole, A0 / B0 of tile 1 -- the order the loop issues in
-    TileAt t1{0, 0, 1u, 0, 0}, t2;  // t1: the tile phases 0 / 1 fill (u + 1), t2: the tile phases 2 / 3 fill (u + 2)
-    t1.ub = (uint32_t)((g.kh0 * g.kw + g.kw0) * g.C) * 2u;
-    issueA(0, t1, 0);
-    issueB(0, t1, 0);
-    issueB(1, t1, 0);
-    issueA(1, t1, 0);
-    advance(t1);
-    if (nt > 1) {
-      issueA(0, t1, 1);
-      issueB(0, t1, 1);
-      FMI_8P_WAIT(WFULL);
-    } else {
-      FMI_8P_WAIT(NA + NB);
-    }
-    t2 = t1;
-    advance(t2);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (grp && !(FMI_8P_EXP & 1)) __builtin_amdgcn_s_barrier();  // the second four waves run one barrier behind
-    int st = 0;
-    // ONE loop body for every reduction tile (two specialised copies -- steady state / last two tiles -- double the code for two
-    // scalar branches per phase; a persistent variant with both copies made the allocator shuffle accumulators where they met)
-    for (int u = 0; u < nt; ++u) {
-      const bool n1 = u + 1 < nt, n2 = u + 2 < nt;
+  // prologue: the first output tile's reduction tile 0 whole, A0 / B0 of tile 1 -- the order the loop issues in
+  Item cur = item_at(worker);
+  TileAt t1, t2;  // t1: the reduction tile phases 0 / 1 fill (one ahead of the MFMAs), t2: the one phases 2 / 3 fill (two ahead)
+  enter_item(t1, cur);
+  build_ctx(0, cur.m0, cur.n0);
+  build_ctx(1, cur.m0, cur.n0);
+  issueA(0, t1, 0);
+  issueB(0, t1, 0);
+  issueB(1, t1, 0);
+  issueA(1, t1, 0);
+  advance(t1);  // K >= 128: still inside the first output tile
+  issueA(0, t1, 1);
+  issueB(0, t1, 1);
+  t2 = t1;
+  advance(t2);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA + 2 * NB) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp && !(FMI_8P_EXP & 1)) __builtin_amdgcn_s_barrier();  // the second four waves run one barrier behind
+  int st = 0;
+  int prev = cur.idx;
+  // ONE loop body for every reduction tile (two specialised copies of it -- steady state / tile boundaries -- made the register
+  // allocator shuffle and spill accumulators where they met): the rare paths are uniform branches, the wait counts two-way choices
+  constexpr int WFULL = 2 * NA + 2 * NB;
+#define FMI_8P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+  bool have_prev = false;
+  while (true) {
+    for (int u = 0; u < cur.nt; ++u) {
+      const bool n1 = t1.idx >= 0, n2 = t2.idx >= 0;
       // phase 0: quadrant (i0, j0)
+      if (have_prev && u == 0) {  // the operand registers are free here: the finished output tile leaves, its accumulators restart
+        out_quadrant(prev, 0, 0);
+        out_quadrant(prev, 0, 1);
+        out_quadrant(prev, 1, 1);
+        out_quadrant(prev, 1, 0);
+      }
+      if (n1 && t1.kt == 0) {  // the stream one tile ahead has entered the next output tile: contexts of its A1 / B1 rows
+        const Item it = item_at(t1.idx);
+        build_ctx(1, it.m0, it.n0);
+      }
       read_b(st, 0, bw0);
       __builtin_amdgcn_sched_barrier(0);
       read_a(st, 0);
@@ -299,6 +420,10 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
       mfmas(acc[0][1], bw1);
       FMI_8P_END();
       // phase 2: (i1, j1)
+      if (n2 && t2.kt == 0) {  // the stream two tiles ahead has entered the next output tile: contexts of its A0 / B0 rows
+        const Item it = item_at(t2.idx);
+        build_ctx(0, it.m0, it.n0);
+      }
       read_a(st, 1);
       if (n2) issueA(0, t2, st);
       FMI_8P_MID();
@@ -320,68 +445,18 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
       FMI_8P_END();
       st ^= 1;
     }
-    if (!grp && !(FMI_8P_EXP & 1)) __builtin_amdgcn_s_barrier();
+    prev = cur.idx;
+    have_prev = true;
+    const int next = cur.idx + G;
+    if (next >= work.total) break;
+    cur = item_at(next);
   }
+#undef FMI_8P_WAIT
+  if (!grp && !(FMI_8P_EXP & 1)) __builtin_amdgcn_s_barrier();
 #undef FMI_8P_MID
 #undef FMI_8P_END
-#undef FMI_8P_WAIT
-
-  // ---- output: lane = pixel (l & 15) of each 16-pixel group, four consecutive channels 4 (l >> 4) .. + 3 of each 16-channel group
-  const ConvEpB ep = set.ph[blockIdx.y].ep;
-  const int M = set.ph[blockIdx.y].M, N = set.N;
-  const int cl = 4 * (lane >> 4);
-  if (FMI_8P_EXP & 32) {  // timing: no output stage at all (one store that keeps the accumulators alive)
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) t += acc[i][j][r][c][0] + acc[i][j][r][c][1] + acc[i][j][r][c][2] + acc[i][j][r][c][3];
-    if (t == 123.25f) ep.y[0] = 1;
-    return;
-  }
-  const float nwv = (act.on && act.noise) ? act.nw[0] : 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wr * 128 + i * 64 + r * 16 + l15;
-      if (row >= M) continue;
-      int n_s = 0;
-      const int64_t pix = ep.row_pix(row, n_s), off = pix * ep.cstride;
-      float nz = 0.f;
-      if (act.on && act.noise) nz = nwv * act.noise[pix];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int col = n0 + wc * 64 + j * 32 + c * 16 + cl;
-          if (col >= N) continue;
-          f32x4v a = acc[i][j][r][c];
-          if (ep.colscale) {
-            const float4 cs = *reinterpret_cast<const float4*>(ep.colscale + (int64_t)n_s * ep.Nout + col);
-            a[0] *= cs.x, a[1] *= cs.y, a[2] *= cs.z, a[3] *= cs.w;
-          }
-          if (act.on) {
-            float4 b = {0.f, 0.f, 0.f, 0.f};
-            if (act.bias) b = *reinterpret_cast<const float4*>(act.bias + col);
-            const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float v = a[e] + nz + bb[e];
-              a[e] = (v < 0.f ? v * act.slope : v) * act.gain;
-            }
-          }
-          const bf16x2v lo = __builtin_convertvector((f32x2v){a[0], a[1]}, bf16x2v), hi = __builtin_convertvector((f32x2v){a[2], a[3]}, bf16x2v);
-          uint2 v;
-          v.x = *reinterpret_cast<const uint32_t*>(&lo);
-          v.y = *reinterpret_cast<const uint32_t*>(&hi);
-          if (!(FMI_8P_EXP & 16) || M < 0) *reinterpret_cast<uint2*>(ep.y + off + col) = v;
-        }
-      }
-    }
-  }
+  out_quadrant(prev, 0, 0);
+  out_quadrant(prev, 0, 1);
+  out_quadrant(prev, 1, 1);
+  out_quadrant(prev, 1, 0);
 }
