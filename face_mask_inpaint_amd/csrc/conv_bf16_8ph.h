@@ -22,7 +22,8 @@
 //    (D row = 4 (l >> 4) + r, column = l & 15): 8-byte bf16 stores.
 //  * one output tile per workgroup.  Persistent workgroups with the DMA streams running across output tiles were built and measured
 //    slower (tools/bench_tools/experiments/conv_bf16_8ph_persistent.h: scalar-register pressure); what remains exposed is the
-//    output stage and its store burst -- 6 % / 13 % / 24 % of the launch at 72 / 36 / 18 reduction tiles per output tile.
+//    output stage and its store burst -- 6 % / 13 % / 24 % of the launch at 72 / 36 / 18 reduction tiles per output tile.  Starting
+//    the first round of workgroups spread over 8 us (so that the rounds' store bursts do not coincide) measured 1-3 % slower.
 #pragma once
 #include <type_traits>
 
@@ -50,7 +51,7 @@ struct EpActB {
 };
 
 #ifndef FMI_8P_EXP
-#define FMI_8P_EXP 0  // timing experiments (wrong results except 1, 64): 1 no stagger, 2 no DMA issue, 4 no LDS reads, 8 no MFMAs, 16 no stores, 32 no output stage, 64 staggered start
+#define FMI_8P_EXP 0  // timing experiments (wrong results except 1): 1 no stagger, 2 no DMA issue, 4 no LDS reads, 8 no MFMAs, 16 no stores, 32 no output stage
 #endif
 
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -244,10 +245,6 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
 #define FMI_8P_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
   constexpr int WFULL = 2 * NA + 2 * NB;
 
-  if (FMI_8P_EXP & 64) {  // experiment: the first round of workgroups starts spread over ~8 us, so that the rounds' store bursts do not coincide
-    if (blockIdx.x < 256)
-      for (int i = 0; i < (int)(blockIdx.x & 15); ++i) __builtin_amdgcn_s_sleep(20);
-  }
   if (nt > 0) {
     // prologue: tile 0 whole, A0 / B0 of tile 1 -- the order the loop issues in
     TileAt t1{0, 0, 1u, 0, 0}, t2;  // t1: the tile phases 0 / 1 fill (u + 1), t2: the tile phases 2 / 3 fill (u + 2)
