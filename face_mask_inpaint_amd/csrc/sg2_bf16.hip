@@ -30,6 +30,15 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
   f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
 }
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+typedef __bf16 bf16x2h __attribute__((ext_vector_type(2)));
+typedef float f32x2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf_hw(float a, float b) {  // v_cvt_pk_bf16_f32: round to nearest even, one instruction
+  const bf16x2h r = __builtin_convertvector((f32x2h){a, b}, bf16x2h);
+  return *reinterpret_cast<const uint32_t*>(&r);
+}
+__device__ __forceinline__ uint4 pack8_hw(const float (&f)[8]) {
+  return make_uint4(pack_bf_hw(f[0], f[1]), pack_bf_hw(f[2], f[3]), pack_bf_hw(f[4], f[5]), pack_bf_hw(f[6], f[7]));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // y[n][p][c] = x[n][p][c] * s[n][c]
@@ -428,6 +437,197 @@ extern "C" int fmi_internal_fir_run_launch(const void* in, const float* kernel, 
 #undef RUN_LAUNCH
   return 1;
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// SEPARABLE 4 x 4 FIR (the decoder's Blur and its gradient: the taps are an outer product by construction, model.py:36-45) through
+// LDS, with the rest of a StyledConv's output folded in when asked:
+//   out = lrelu(FIR(in) * colscale[n][c] + nw * noise[n][oy][ox] + bias[c], slope) * gain
+// (stylegan2/model.py:88-91 Blur, :250-252 demodulation, :282-294 NoiseInjection, op/fused_act.py:30-37 FusedLeakyReLU) -- the
+// blurred map, the demodulated map and the noise + bias + activation pass each were a read and a write of the whole activation.
+// What bounds a FIR on 8-channel bf16 vectors is instruction issue, not HBM: at 5 TB/s of in + out a CU has ~250 vector instructions
+// per 16 output bytes, and the column-run kernel above spends ~165 (16 taps x 8 channels, 4.4 global loads with bounds checks and 4.4
+// unpacks per output, a five-instruction software rounding per value).  Here:
+//  * a workgroup owns TH x 29 output pixels x CVT channel vectors; its (TH + 3) x 32 input pixels arrive ONCE by LDS-DMA, one
+//    instruction per image row (32 pixels x 128 bytes = the workgroup's 256 lanes x 16 bytes): the per-lane part of the address is a
+//    constant, a row costs an add and a select;
+//  * a thread keeps 4 rows x 2 columns of outputs and walks the seven input rows: five ds_read_b128 and five unpacks per row feed
+//    two row sums (4 taps each), which feed up to four output rows (1 tap each): 8 + 4 multiplies per output instead of 16;
+//  * pixels p and p ^ 1 trade places in LDS where bit S of p is set (source-side, the DMA writes lane-linear): the even pixels a
+//    16-lane read group touches then alternate between the two halves of a 256-byte bank row;
+//  * v_cvt_pk_bf16_f32 rounds the outputs.
+static __device__ __attribute__((aligned(16))) float blur_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+struct BlurActArgs {
+  const uint4* in;
+  uint4* out;
+  const float* kernel;    // [4][4], rank one
+  const float* colscale;  // [N][C] or null
+  const float* noise;     // [N][OH][OW] or null
+  const float* nw;        // one float, used with noise
+  const float* bias;      // [C] or null
+  float slope, gain;
+  int act;                // 0: plain FIR
+  int N, in_h, in_w, CV, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, cgroups;
+};
+template <int CVT, bool ACT>
+__global__ void __launch_bounds__(256) blur4_lds_bf16_kernel(BlurActArgs a) {
+  constexpr int TWO = 29, R = 4, NRG = 256 / (CVT * 16), TH = R * NRG, IHT = TH + 3;
+  constexpr int RPI = 8 / CVT;                 // image rows per DMA instruction (32 pixels x CVT vectors each)
+  constexpr int NLD = (IHT + RPI - 1) / RPI;   // DMA instructions per thread
+  constexpr int S = CVT == 8 ? 1 : 2;          // swizzle bit
+  __shared__ uint4 tile[NLD * 256];
+  const int tid = threadIdx.x;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int cg = b % a.cgroups;
+  b /= a.cgroups;
+  const int tx = b % a.tiles_x;
+  b /= a.tiles_x;
+  const int ty = b % a.tiles_y, n = b / a.tiles_y;
+  const int ox0 = tx * TWO, oy0 = ty * TH, cv0 = cg * CVT;
+  // ---- input tile: LDS position (row r, pixel slot ps, vector cv) holds image pixel ox0 - pad_x0 + (ps ^ ((ps >> S) & 1))
+  {
+    const int cvl = tid % CVT, ps = (tid / CVT) & 31, rsub = tid / (CVT * 32);
+    const int gx = ox0 - a.pad_x0 + (ps ^ ((ps >> S) & 1));
+    const bool xok = (unsigned)gx < (unsigned)a.in_w;
+    const uint4* col = a.in + (int64_t)n * a.in_h * a.in_w * a.CV + (int64_t)gx * a.CV + cv0 + cvl;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)tile;
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(tid >> 6) * 1024u);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int gy = oy0 - a.pad_y0 + j * RPI + rsub;
+      const bool ok = xok && (unsigned)gy < (unsigned)a.in_h && j * RPI + rsub < IHT;
+      const void* src = ok ? (const void*)(col + (int64_t)gy * a.in_w * a.CV) : (const void*)blur_zero_chunk;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src), "s"(wbase + (uint32_t)j * 4096u)
+                   : "memory");
+    }
+  }
+  float kx[4], ky[4];  // k[i][j] (flipped, as upfirdn2d applies it) = ky[i] * kx[j]
+  {
+    const float k00 = a.kernel[15], inv = 1.f / k00;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kx[j] = a.kernel[15 - j] * inv, ky[j] = a.kernel[(3 - j) * 4 + 3];
+  }
+  const int cv = tid % CVT, xp = (tid / CVT) & 15, rg = tid / (CVT * 16);
+  // LDS vector index of pixel slot for image-order pixel p of the tile row: (p ^ ((p >> S) & 1)) * CVT + cv
+  int slot[5];
+#pragma unroll
+  for (int bb = 0; bb < 5; ++bb) {
+    const int p = 2 * xp + bb;  // <= 34: the last pair's columns lie outside the 29 outputs; clamp keeps the read inside the row
+    const int pc = p < 32 ? p : 31;
+    slot[bb] = (pc ^ ((pc >> S) & 1)) * CVT + cv;
+  }
+  float acc[R][2][8];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[q][0][e] = 0.f, acc[q][1][e] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < R + 3; ++t) {
+    const uint4* row = tile + (rg * R + t) * 32 * CVT;
+    float h0[8], h1[8];
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) {
+      float v[8];
+      unpack8(row[slot[bb]], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (bb < 4) h0[e] = bb == 0 ? v[e] * kx[0] : fmaf(v[e], kx[bb], h0[e]);
+        if (bb > 0) h1[e] = bb == 1 ? v[e] * kx[0] : fmaf(v[e], kx[bb - 1], h1[e]);
+      }
+    }
+    // the next row's LDS reads stay behind this row's sums (a bare memory clobber does not do it: nothing ties it to the
+    // arithmetic, and with all 35 vectors read up front the kernel needed 250 registers)
+    asm volatile(""
+                 : "+v"(h0[0]), "+v"(h0[1]), "+v"(h0[2]), "+v"(h0[3]), "+v"(h0[4]), "+v"(h0[5]), "+v"(h0[6]), "+v"(h0[7]), "+v"(h1[0]), "+v"(h1[1]),
+                   "+v"(h1[2]), "+v"(h1[3]), "+v"(h1[4]), "+v"(h1[5]), "+v"(h1[6]), "+v"(h1[7])::"memory");
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int ta = t - q;  // tap row (compile-time after unrolling)
+      if (ta < 0 || ta >= 4) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[q][0][e] = fmaf(h0[e], ky[ta], acc[q][0][e]), acc[q][1][e] = fmaf(h1[e], ky[ta], acc[q][1][e]);
+    }
+  }
+  const int oxa = ox0 + 2 * xp;
+  const int xlim = ox0 + TWO < a.out_w ? ox0 + TWO : a.out_w;
+  if (oxa >= xlim) return;
+  const bool two = oxa + 1 < xlim;
+  const int c = (cv0 + cv) * 8;
+  float d[8], bs[8];
+  if (ACT) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = 1.f, bs[e] = 0.f;
+    if (a.colscale) load8f(a.colscale + (int64_t)n * a.CV * 8 + c, d);
+    if (a.bias) load8f(a.bias + c, bs);
+  }
+  const float nwv = (ACT && a.noise) ? a.nw[0] : 0.f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int oy = oy0 + rg * R + q;
+    if (oy >= a.out_h) break;
+    const int64_t pix = ((int64_t)n * a.out_h + oy) * a.out_w + oxa;
+    if (ACT) {
+      float nz0 = 0.f, nz1 = 0.f;
+      if (a.noise) nz0 = nwv * a.noise[pix], nz1 = two ? nwv * a.noise[pix + 1] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float u0 = acc[q][0][e] * d[e] + nz0 + bs[e], u1 = acc[q][1][e] * d[e] + nz1 + bs[e];
+        acc[q][0][e] = (u0 < 0.f ? u0 * a.slope : u0) * a.gain;
+        acc[q][1][e] = (u1 < 0.f ? u1 * a.slope : u1) * a.gain;
+      }
+    }
+    uint4* o = a.out + pix * a.CV + cv0 + cv;
+    o[0] = pack8_hw(acc[q][0]);
+    if (two) o[a.CV] = pack8_hw(acc[q][1]);
+  }
+}
+extern "C" int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh,
+                                       int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                                       void* stream);
+static int blur4_lds_launch(BlurActArgs& a, int C, hipStream_t st) {
+  const bool wide = C % 64 == 0;
+  const int cvt = wide ? 8 : 4, th = wide ? 8 : 16;
+  a.CV = C / 8;
+  a.cgroups = a.CV / cvt;
+  a.tiles_x = (a.out_w + 28) / 29;
+  a.tiles_y = (a.out_h + th - 1) / th;
+  const int64_t nwg = (int64_t)a.N * a.tiles_y * a.tiles_x * a.cgroups;
+  if (nwg > 0x7fffffffLL) return FMI_ERR_UNSUPPORTED;
+#define BLUR_GO(CVT_, ACT_) hipLaunchKernelGGL((blur4_lds_bf16_kernel<CVT_, ACT_>), dim3((unsigned)nwg), dim3(256), 0, st, a)
+  if (wide) {
+    if (a.act) BLUR_GO(8, true);
+    else BLUR_GO(8, false);
+  } else {
+    if (a.act) BLUR_GO(4, true);
+    else BLUR_GO(4, false);
+  }
+#undef BLUR_GO
+  return fmi_launch_status();
+}
+/* out = lrelu(FIR4x4(in) * colscale[n][c] + nw * noise[n][oy][ox] + bias[c], slope) * gain on bf16 NHWC maps: the Blur of an
+ * upsampling StyledConv with the demodulation, NoiseInjection and FusedLeakyReLU that follow it (any of colscale / noise / bias may be
+ * null; nw is required with noise).  kernel: 16 fp32 taps (upfirdn2d's orientation). */
+extern "C" int fmi_blur_act_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int pad_x0,
+                                 int pad_x1, int pad_y0, int pad_y1, const float* colscale, const float* noise, const float* nw,
+                                 const float* bias, float slope, float gain, int separable, void* stream) {
+  if (!in || !kernel || !out || N <= 0 || in_h <= 0 || in_w <= 0 || C <= 0 || (noise && !nw)) return FMI_ERR_BAD_ARG;
+  const int out_h = in_h + pad_y0 + pad_y1 - 3, out_w = in_w + pad_x0 + pad_x1 - 3;
+  if (out_h <= 0 || out_w <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 32 != 0 || !al16(in) || !al16(out) || (colscale && !al16(colscale)) || (bias && !al16(bias))) return FMI_ERR_UNSUPPORTED;
+  BlurActArgs a{};
+  a.in = (const uint4*)in; a.out = (uint4*)out; a.kernel = kernel;
+  a.colscale = colscale; a.noise = noise; a.nw = nw; a.bias = bias; a.slope = slope; a.gain = gain; a.act = (colscale || noise || bias || slope != 1.f || gain != 1.f) ? 1 : 0;
+  if (!separable) {  // general taps: the plain FIR through fmi_upfirdn2d_nhwc_bf16's kernels, no fused form
+    if (a.act) return FMI_ERR_UNSUPPORTED;
+    return fmi_upfirdn2d_nhwc_bf16(in, kernel, out, N, in_h, in_w, C, 4, 4, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+  }
+  a.N = N; a.in_h = in_h; a.in_w = in_w; a.out_h = out_h; a.out_w = out_w; a.pad_x0 = pad_x0; a.pad_y0 = pad_y0;
+  return blur4_lds_launch(a, C, (hipStream_t)stream);
+}
+
 extern "C" int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh,
                                        int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                                        void* stream) {

@@ -230,6 +230,15 @@ int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y, const floa
                                 float* ws, int64_t ws_floats, int64_t pixels, int C, float alpha, float scale, void* stream);
 int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int kh, int kw,
                             int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* out = lrelu(FIR4x4(in) * colscale[n][c] + nw[0] * noise[n][oy][ox] + bias[c], slope) * gain on bf16 NHWC maps in ONE pass: the Blur of
+ * an upsampling StyledConv (stylegan2/model.py:88-91, 268-271) together with the demodulation (:250-252), NoiseInjection (:282-294)
+ * and FusedLeakyReLU (op/fused_act.py:30-37) that follow it.  in [N][in_h][in_w][C], out [N][in_h+pad_y0+pad_y1-3][in_w+pad_x0+pad_x1-3][C];
+ * kernel: 16 fp32 taps in upfirdn2d's orientation; colscale [N][C], noise [N][OH][OW], bias [C] may each be NULL; C % 32 == 0.
+ * separable != 0: the caller states that the taps are an outer product k[i][j] = ky[i] kx[j] (the Blur's kernel is one by construction,
+ * model.py:36-45) with k[0][0] != 0; the kernel then filters rows and columns in turn (8 multiplies per output instead of 16). */
+int fmi_blur_act_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int pad_x0, int pad_x1,
+                      int pad_y0, int pad_y1, const float* colscale, const float* noise, const float* nw, const float* bias, float slope,
+                      float gain, int separable, void* stream);
 int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float* s, const float* bias, const float* skip, float* out, int N,
                        int64_t P, int C, void* stream);
 int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* ws, int64_t ws_floats,

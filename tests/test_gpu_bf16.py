@@ -171,6 +171,45 @@ def test_conv_bf16_rejects_unsupported(dev, FF):
         lib.conv2d_fwd_bf16(C.byref(d), FF._p(x), FF._p(w), None, FF._p(y), None, 0, FF._st())
 
 
+@pytest.mark.parametrize("n,h,w,c,pad", [(2, 17, 17, 64, (1, 1)), (1, 33, 31, 128, (1, 1)), (3, 8, 8, 32, (2, 2)), (2, 5, 6, 96, (2, 1)),
+                                         (1, 65, 65, 512, (1, 1)), (2, 20, 37, 160, (2, 2))])
+def test_blur_lds_and_fused_output_stage(dev, FF, n, h, w, c, pad):
+    """fmi_upfirdn2d_nhwc_bf16's 4 x 4 path (LDS-tiled) against a float64 FIR of the same bf16 input at one-rounding tolerance, and
+    fmi_blur_act_bf16 = that FIR + demodulation + noise + bias + leaky ReLU in one pass against the composition evaluated in float64
+    (model.py:88-91, 250-252, 282-294, op/fused_act.py:30-37); tile-edge sizes, both channel-group widths, both pad pairs"""
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(n * 131 + h * 7 + c)
+    x = bf(torch.randn(n, h, w, c, generator=g))
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = (k[:, None] * k[None, :]) / 64 * 4
+    oh, ow = h + pad[0] + pad[1] - 3, w + pad[0] + pad[1] - 3
+    ref = F.conv2d(F.pad(x.double().permute(0, 3, 1, 2), (pad[0], pad[1], pad[0], pad[1])).reshape(n * c, 1, h + pad[0] + pad[1], w + pad[0] + pad[1]),
+                   torch.flip(k2, [0, 1]).double().view(1, 1, 4, 4)).view(n, c, oh, ow).permute(0, 2, 3, 1)
+    xd, kd, st = x.to(dev), k2.to(dev), FF._st()
+    y = torch.full((n, oh, ow, c), float("nan"), dtype=BF, device=dev)
+    lib.upfirdn2d_nhwc_bf16(FF._p(xd), FF._p(kd), FF._p(y), n, h, w, c, 4, 4, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1], st)
+    close_bf16(y, ref.float())
+    d = (torch.rand(n, c, generator=g) + 0.5)
+    bias, noise, nw = torch.randn(c, generator=g), torch.randn(n, oh, ow, generator=g), torch.randn(1, generator=g)
+    for use in ((True, True, True, 1), (True, False, False, 1), (False, True, True, 1), (False, False, True, 1), (False, False, False, 1), (False, False, False, 0)):
+        dd, nn, bb = (d.to(dev) if use[0] else None), (noise.to(dev) if use[1] else None), (bias.to(dev) if use[2] else None)
+        y2 = torch.full((n, oh, ow, c), float("nan"), dtype=BF, device=dev)
+        plain = not any(use[:3])  # no output stage: slope 1, gain 1 (the separable FIR alone / the general-tap fallback)
+        lib.blur_act_bf16(FF._p(xd), FF._p(kd), FF._p(y2), n, h, w, c, pad[0], pad[1], pad[0], pad[1], FF._p(dd), FF._p(nn),
+                          FF._p(nw.to(dev)), FF._p(bb), 1.0 if plain else 0.2, 1.0 if plain else 2 ** 0.5, use[3], st)
+        if plain:
+            close_bf16(y2, ref.float())
+            continue
+        pre = ref * (d.double().view(n, 1, 1, c) if use[0] else 1.0)
+        if use[1]:
+            pre = pre + nw.double() * noise.double().unsqueeze(-1)
+        if use[2]:
+            pre = pre + bias.double()
+        close_bf16(y2, (F.leaky_relu(pre, 0.2) * 2 ** 0.5).float())
+
+
 @pytest.mark.parametrize("n,h,w,c", [(2, 9, 7, 64), (3, 16, 16, 512), (1, 5, 6, 32)])
 def test_bf16_elementwise(dev, FF, n, h, w, c):
     g = torch.Generator().manual_seed(n * 31 + c)
