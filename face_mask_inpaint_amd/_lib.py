@@ -72,6 +72,8 @@ SIGNATURES = {
     "fmi_noise_bias_act_bf16": [vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     "fmi_noise_bias_act_bwd_bf16": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, f32, f32, vp],
     "fmi_upfirdn2d_nhwc_bf16": [vp, vp, vp] + [i32] * 14 + [vp],
+    "fmi_styled_out_bwd_bf16": [vp] * 11 + [i64, vp, i32, i64, i32, f32, f32, vp],
+    "fmi_conv2d_fwd_act_bf16": [PD, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp],
     "fmi_blur_act_bf16": [vp, vp, vp] + [i32] * 8 + [vp, vp, vp, vp, f32, f32, i32, vp],
     "fmi_torgb_fwd_bf16": [vp, vp, vp, vp, vp, vp, i32, i64, i32, vp],
     "fmi_torgb_bwd_bf16": [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i64, i32, vp],

@@ -456,8 +456,8 @@ extern "C" int fmi_conv2d_bf16_supported(const fmi_conv_desc* d) {
   return d->C % 32 == 0 && d->K % 32 == 0 && d->x_cstride % 8 == 0 && d->y_cstride % 8 == 0;
 }
 
-extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y,
-                                   float* ws, int64_t ws_floats, void* stream) {
+static int conv2d_fwd_bf16_impl(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y, float* ws,
+                               int64_t ws_floats, const EpActB* act, void* stream) {
   int rc = check_desc_b(d);
   if (rc) return rc;
   if (!x || !wnk || !y) return FMI_ERR_BAD_ARG;
@@ -479,10 +479,25 @@ extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, co
   set.ph[0].K = g.Kdim();
   const int64_t out_elems = (int64_t)d->N * d->OH * d->OW * d->y_cstride;
   if (ws && (((uintptr_t)ws & 15) || ((uintptr_t)y & 7))) ws = nullptr;
-  if (d->C % 64 == 0) return launch_conv_bf16<64>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream);
-  return launch_conv_bf16<32>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream);
+  if (d->C % 64 == 0) return launch_conv_bf16<64>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream, act);
+  return launch_conv_bf16<32>(set, 1, d->K, y, ws, ws_floats, out_elems, (hipStream_t)stream, act);
 }
 
+extern "C" int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y,
+                                   float* ws, int64_t ws_floats, void* stream) {
+  return conv2d_fwd_bf16_impl(d, x, wnk, colscale, y, ws, ws_floats, nullptr, stream);
+}
+/* y = lrelu(conv(x, W) * colscale[n][k] + nw[0] * noise[n][oy][ox] + bias[k], slope) * gain: a StyledConv without upsampling in one
+ * launch (stylegan2/model.py:241-279 ModulatedConv2d on pre-scaled activations, :250-252 demodulation, :282-294 NoiseInjection,
+ * op/fused_act.py:30-37 FusedLeakyReLU) -- the output stage of the eight-phase kernel (csrc/conv_bf16_8ph.h).  colscale / noise / bias
+ * may be NULL; FMI_ERR_UNSUPPORTED where that kernel does not apply (C % 64, K % 4 and K > 64, 8-byte aligned y, 16-byte colscale / bias). */
+extern "C" int fmi_conv2d_fwd_act_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, const float* noise,
+                                       const float* nw, const float* bias, float slope, float gain, uint16_t* y, void* stream) {
+  if (noise && !nw) return FMI_ERR_BAD_ARG;
+  if (bias && ((uintptr_t)bias & 15)) return FMI_ERR_UNSUPPORTED;
+  EpActB act{noise, nw, bias, slope, gain, 1};
+  return conv2d_fwd_bf16_impl(d, x, wnk, colscale, y, nullptr, 0, &act, stream);
+}
 /* dx = adjoint of the convolution described by d applied to dy; wck = weights packed [C][kh*kw][K] */
 extern "C" int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx,
                                      float* ws, int64_t ws_floats, void* stream) {

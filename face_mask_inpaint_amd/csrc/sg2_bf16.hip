@@ -281,6 +281,107 @@ extern "C" int fmi_noise_bias_act_bwd_bf16(const uint16_t* g, const uint16_t* y,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Adjoint of the fused StyledConv output stage  y = lrelu(z * d[n][c] + nw * noise[n][p] + bias[c], slope) * gain  (z: the Blur's /
+// the convolution's fp32 result; fmi_blur_act_bf16, fmi_conv2d_fwd_act_bf16) in ONE pass over g and y:
+//   gpre = g * gain * (y > 0 ? 1 : slope)                       t[n][p][c] = gpre * d[n][c]   (gradient wrt z, bf16)
+//   gbias[c] = sum_{n,p} gpre        gnw = sum gpre * noise     gd[n][c] = sum_p gpre * z
+// z itself was never stored: gpre * (z d + nw noise + bias) = g * y exactly (both branches of the leaky ReLU), so
+//   gd[n][c] = (sum_p g y - nw sum_p gpre noise - bias[c] sum_p gpre) / d[n][c].
+// The unfused chain was three passes (noise_bias_act_bwd, scale_channels, scale_channels_gs: 4 reads and 2 writes of the map).
+// ws: per (sample, row block) three rows of C floats: sum g y, sum gpre noise, sum gpre.
+__global__ void __launch_bounds__(256) styled_out_bwd_bf16_kernel(const uint4* __restrict__ g, const uint4* __restrict__ y,
+                                                                  const float* __restrict__ noise, const float* __restrict__ colscale,
+                                                                  uint4* __restrict__ t, float* __restrict__ ws, int64_t P, int C8,
+                                                                  float slope, float gain, int64_t rows_per_block) {
+  __shared__ float part[256][8];
+  const int RL = 256 / C8, cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int n = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const uint4* gb = g + (int64_t)n * P * C8;
+  const uint4* yb = y + (int64_t)n * P * C8;
+  uint4* tb = t + (int64_t)n * P * C8;
+  const float* nb = noise ? noise + (int64_t)n * P : nullptr;
+  float d[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) d[e] = 1.f;
+  if (colscale) load8f(colscale + ((int64_t)n * C8 + cg) * 8, d);
+  float sa[8], sb[8], sc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sa[e] = 0.f, sb[e] = 0.f, sc[e] = 0.f;
+  auto one = [&](int64_t r, const uint4& gv, const uint4& yv) {
+    float a[8], b[8];
+    unpack8(gv, a);
+    unpack8(yv, b);
+    const float nz = nb ? nb[r] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sa[e] = fmaf(a[e], b[e], sa[e]);
+      const float gp = a[e] * gain * (b[e] > 0.f ? 1.f : slope);
+      sb[e] = fmaf(gp, nz, sb[e]);
+      sc[e] += gp;
+      a[e] = gp * d[e];
+    }
+    tb[r * C8 + cg] = pack8_hw(a);
+  };
+  int64_t r = r0 + rl;
+  for (; r + RL < r1; r += 2 * RL) {  // two independent pairs of 16-byte loads in flight
+    const uint4 g0 = gb[r * C8 + cg], y0 = yb[r * C8 + cg], g1 = gb[(r + RL) * C8 + cg], y1 = yb[(r + RL) * C8 + cg];
+    one(r, g0, y0);
+    one(r + RL, g1, y1);
+  }
+  for (; r < r1; r += RL) one(r, gb[r * C8 + cg], yb[r * C8 + cg]);
+  float* row = ws + ((int64_t)n * gridDim.x + blockIdx.x) * 3 * C8 * 8;
+  chunk_reduce_store(sa, row, C8, part);
+  chunk_reduce_store(sb, row + C8 * 8, C8, part);
+  chunk_reduce_store(sc, row + 2 * C8 * 8, C8, part);
+}
+// sums[n][3][C] -> gd[n][c], gbias[c], gnw (one block; N * C is a few thousand)
+__global__ void __launch_bounds__(256) styled_out_finish_kernel(const float* __restrict__ sums, const float* __restrict__ colscale,
+                                                                const float* __restrict__ nw, const float* __restrict__ bias,
+                                                                float* __restrict__ gd, float* __restrict__ gbias, float* __restrict__ gnw,
+                                                                int N, int C) {
+  __shared__ float red[4];
+  const float nwv = nw ? nw[0] : 0.f;
+  float tn = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float bv = bias ? bias[c] : 0.f;
+    float tb = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float* s = sums + (int64_t)n * 3 * C;
+      const float A = s[c], B = s[C + c], Cs = s[2 * C + c];
+      if (gd) gd[(int64_t)n * C + c] = (A - nwv * B - bv * Cs) / (colscale ? colscale[(int64_t)n * C + c] : 1.f);
+      tb += Cs;
+      tn += B;
+    }
+    if (gbias) gbias[c] = tb;
+  }
+  tn = block_sum_256(tn, red);
+  if (gnw && threadIdx.x == 0) gnw[0] = tn;
+}
+/* t = gradient wrt the pre-demodulation map (bf16), gd [N][C], gbias [C], gnw [1] (each of the three may be NULL); noise, colscale, nw,
+ * bias as the forward was given them (NULL where it had none).  ws: >= N * 3 * C floats (more = more row blocks); sums: N * 3 * C floats. */
+extern "C" int fmi_styled_out_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, const float* colscale, const float* nw,
+                                       const float* bias, uint16_t* t, float* gd, float* gbias, float* gnw, float* ws, int64_t ws_floats,
+                                       float* sums, int N, int64_t P, int C, float slope, float gain, void* stream) {
+  if (!g || !y || !t || !ws || !sums || N <= 0 || P <= 0 || C <= 0 || (noise && !nw)) return FMI_ERR_BAD_ARG;
+  if (!c8_ok(C) || !al16(g) || !al16(y) || !al16(t) || !al16(ws) || (colscale && !al16(colscale))) return FMI_ERR_UNSUPPORTED;
+  if (ws_floats < (int64_t)N * 3 * C) return FMI_ERR_BAD_ARG;
+  int64_t blocks = parts_for(P, N, 3 * (int64_t)C, ws_floats);
+  const int64_t rpb = ceil_div64(P, blocks);
+  blocks = ceil_div64(P, rpb);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(styled_out_bwd_bf16_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0, st, (const uint4*)g, (const uint4*)y, noise,
+                     colscale, (uint4*)t, ws, P, C / 8, slope, gain, rpb);
+  launch_sum_parts(ws, sums, (int)blocks, 3 * C, N, st);
+  if (gd || gbias || gnw)
+    hipLaunchKernelGGL(styled_out_finish_kernel, dim3(1), dim3(256), 0, st, sums, colscale, noise ? nw : nullptr, bias, gd, gbias,
+                       noise ? gnw : nullptr, N, C);
+  return fmi_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // upfirdn2d on NHWC bf16, FIR form (up = down = 1, square kernel of 2..4 taps: the decoder's Blur and its gradient).  One thread =
 // (2 adjacent output pixels, 8 channels); the KH x (KW+1) window is read once with 16-byte loads; fp32 taps and accumulation.
 template <int KH, int KW>

@@ -632,6 +632,120 @@ class _ConvTranspose2dBF16(torch.autograd.Function):
         return gx, gwf, None, None, None, None, None, None
 
 
+def _styled_out_bwd(g, y, noise, d, nw, bias, slope, gain, need_d, need_b, need_nw):
+    """adjoint of the fused StyledConv output stage (fmi_styled_out_bwd_bf16): one pass over g and y -> (t, gd, gbias, gnw)"""
+    n, c = y.shape[0], y.shape[-1]
+    p = y.numel() // (n * c)
+    t = torch.empty_like(y)
+    gd = torch.empty((n, c), device=y.device, dtype=torch.float32) if (need_d and d is not None) else None
+    gb = torch.empty(c, device=y.device, dtype=torch.float32) if (need_b and bias is not None) else None
+    gnw = torch.empty(1, device=y.device, dtype=torch.float32) if (need_nw and noise is not None) else None
+    ws = _parts_ws(y.device, max(2048, n) * 3 * c)
+    sums = torch.empty(n * 3 * c, device=y.device, dtype=torch.float32)
+    with _prof(f"bytes:noise_bias_act_fused_bwd|{tuple(y.shape)}", 3.0 * y.element_size() * y.numel()):
+        _L().styled_out_bwd_bf16(_p(g), _p(y), _p(noise), _p(d), _p(nw), _p(bias), _p(t), _p(gd), _p(gb), _p(gnw), _p(ws), ws.numel(), _p(sums),
+                                 n, p, c, slope, gain, _st())
+    return t, gd, gb, gnw
+
+
+class _StyledConvBF16(torch.autograd.Function):
+    """y = lrelu(conv(x, W) * d[n][k] + nw * noise + bias, slope) * gain on bf16 NHWC activations in ONE forward launch (the output
+    stage of the eight-phase kernel) and one fused adjoint pass in front of the convolution's own gradients: ModulatedConv2d on
+    pre-scaled activations + demodulation + NoiseInjection + FusedLeakyReLU (stylegan2/model.py:241-294, op/fused_act.py:30-69)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, wt, d, noise, nw, bias, kh, kw, pad, slope, gain):
+        _chk(x, dtype=BF16)
+        _chk(wf, wt, d, noise, nw, bias)
+        lib = _L()
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        dsc, oh, ow = conv_desc(n, h, w, c, k, kh, kw, 1, pad)
+        y = torch.empty((n, oh, ow, k), device=x.device, dtype=BF16)
+        wnk = _pack_bf16(wf)
+        with _prof(f"conv_fwd_bf16|{n}x{h}x{w} {c}->{k} k{kh}s1 +out", 2.0 * n * oh * ow * k * c * kh * kw):
+            lib.conv2d_fwd_act_bf16(C.byref(dsc), _p(x), _p(wnk), _p(d), _p(noise), _p(nw), _p(bias), slope, gain, _p(y), _st())
+        ctx.save_for_backward(x, wf, wt, d, noise, nw, bias, y)
+        ctx.cfg = (kh, kw, pad, slope, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _L()
+        x, wf, wt, d, noise, nw, bias, y = ctx.saved_tensors
+        kh, kw, pad, slope, gain = ctx.cfg
+        n, h, w, c = x.shape
+        k = wf.shape[2]
+        ni = ctx.needs_input_grad
+        t, gd, gb, gnw = _styled_out_bwd(g.contiguous(), y, noise, d, nw, bias, slope, gain, ni[3], ni[6], ni[5])
+        dsc, _, _ = conv_desc(n, h, w, c, k, kh, kw, 1, pad)
+        gx = gwf = None
+        if ni[0]:
+            gx = torch.empty_like(x)
+            wck = _pack_bf16(wt)
+            ws, wsn = _split_ws(gx, k * kh * kw)
+            with _prof(f"conv_dgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s1", 2.0 * t.numel() * c * kh * kw):
+                lib.conv2d_dgrad_bf16(C.byref(dsc), _p(t), _p(wck), None, _p(gx), _p(ws), wsn, _st())
+        if ni[1]:
+            gwf = _zeros_like(wf)
+            with _prof(f"conv_wgrad_bf16|{n}x{h}x{w} {c}->{k} k{kh}s1", 2.0 * t.numel() * c * kh * kw):
+                lib.conv2d_wgrad_bf16(C.byref(dsc), _p(x), _p(t), _p(gwf), _st())
+        return gx, gwf, None, gd, None, gnw, gb, None, None, None, None, None
+
+
+def styled_conv_fused_ok(x, pw: PackedWeight, pad) -> bool:
+    """shapes the fused StyledConv launch takes (the eight-phase kernel's conditions) and where it pays: the decoder's large maps"""
+    if x.dtype != BF16 or not x.is_cuda:
+        return False
+    n, h, w, c = x.shape
+    k = pw.wf.shape[2]
+    oh, ow = h + 2 * pad - pw.kh + 1, w + 2 * pad - pw.kw + 1
+    return c % 64 == 0 and k % 4 == 0 and k > 64 and pw.kh * pw.kw <= 32 and n * oh * ow >= 32768
+
+
+def styled_conv(x, pw: PackedWeight, d, noise, nw, bias, slope, gain, pad):
+    return _StyledConvBF16.apply(x, pw.wf, pw.wt, d, noise, nw, bias, pw.kh, pw.kw, int(pad), float(slope), float(gain))
+
+
+class _BlurActBF16(torch.autograd.Function):
+    """y = lrelu(Blur(u) * d[n][c] + nw * noise + bias, slope) * gain in one pass (fmi_blur_act_bf16): the Blur after an upsampling
+    ModulatedConv2d with the demodulation, NoiseInjection and FusedLeakyReLU behind it (stylegan2/model.py:88-91, 250-252, 268-294)."""
+
+    @staticmethod
+    def forward(ctx, u, kernel, d, noise, nw, bias, pad0, pad1, slope, gain):
+        _chk(u, dtype=BF16)
+        _chk(kernel, d, noise, nw, bias)
+        n, h, w, c = u.shape
+        oh, ow = h + pad0 + pad1 - 3, w + pad0 + pad1 - 3
+        y = torch.empty((n, oh, ow, c), device=u.device, dtype=BF16)
+        with _prof(f"bytes:upfirdn2d|{n}x{h}x{w}x{c} up1 down1 +out", float(u.element_size()) * (u.numel() + y.numel())):
+            _L().blur_act_bf16(_p(u), _p(kernel), _p(y), n, h, w, c, pad0, pad1, pad0, pad1, _p(d), _p(noise), _p(nw), _p(bias), slope, gain, 1, _st())
+        ctx.save_for_backward(kernel, d, noise, nw, bias, y)
+        ctx.cfg = (pad0, pad1, slope, gain, (n, h, w, c))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        kernel, d, noise, nw, bias, y = ctx.saved_tensors
+        pad0, pad1, slope, gain, (n, h, w, c) = ctx.cfg
+        ni = ctx.needs_input_grad
+        t, gd, gb, gnw = _styled_out_bwd(g.contiguous(), y, noise, d, nw, bias, slope, gain, ni[2], ni[5], ni[4])
+        gu = None
+        if ni[0]:
+            oh, ow = y.shape[1], y.shape[2]
+            gk = torch.flip(kernel, [0, 1]).contiguous()
+            g0, g1 = 3 - pad0, h - oh + pad0  # the adjoint FIR's pads (op/upfirdn2d.py:108-113 with up = down = 1)
+            gu = torch.empty((n, h, w, c), device=g.device, dtype=BF16)
+            with _prof(f"bytes:upfirdn2d_bwd|{n}x{h}x{w}x{c} up1 down1", float(t.element_size()) * (t.numel() + gu.numel())):
+                _L().blur_act_bf16(_p(t), _p(gk), _p(gu), n, oh, ow, c, g0, g1, g0, g1, None, None, None, None, 1.0, 1.0, 1, _st())
+        return gu, None, gd, None, gnw, gb, None, None, None, None
+
+
+def blur_act(u, kernel, pad, d, noise, nw, bias, slope, gain):
+    """kernel: the Blur's 4 x 4 taps (an outer product by construction)"""
+    return _BlurActBF16.apply(u, kernel.contiguous(), d, noise, nw, bias, int(pad[0]), int(pad[1]), float(slope), float(gain))
+
+
 def _parts_ws(device, floats: int) -> torch.Tensor:
     """partials workspace of the bf16 reduction passes (contents irrelevant, fully overwritten before it is read)"""
     return torch.empty(int(floats), device=device, dtype=torch.float32)
@@ -1851,17 +1965,22 @@ class _UpFirDnNHWC(torch.autograd.Function):
     op/upfirdn2d.py:108-113."""
 
     @staticmethod
-    def forward(ctx, x, kernel, up, down, pad):
+    def forward(ctx, x, kernel, up, down, pad, separable=False):
         _chk(x, dtype=x.dtype)
         _chk(kernel)
         n, h, w, c = x.shape
         kh, kw = kernel.shape
+        # rank-one 4 x 4 taps on bf16 maps (the decoder's Blur): the separable LDS kernel, forward and adjoint
+        ctx.sep = bool(separable) and x.dtype == BF16 and up == 1 and down == 1 and kh == 4 and kw == 4 and c % 32 == 0
         oh = (h * up + pad[0] + pad[1] - kh) // down + 1
         ow = (w * up + pad[0] + pad[1] - kw) // down + 1
         y = torch.empty((n, oh, ow, c), device=x.device, dtype=x.dtype)
         # bandwidth kernel: the profile record carries algorithmic BYTES (in + out), tag prefix "bytes:"
         with _prof(f"bytes:upfirdn2d|{n}x{h}x{w}x{c} up{up} down{down}", float(x.element_size()) * (x.numel() + y.numel())):
-            (_L().upfirdn2d_nhwc_bf16 if x.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
+            if ctx.sep:
+                _L().blur_act_bf16(_p(x), _p(kernel), _p(y), n, h, w, c, pad[0], pad[1], pad[0], pad[1], None, None, None, None, 1.0, 1.0, 1, _st())
+            else:
+                (_L().upfirdn2d_nhwc_bf16 if x.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(x), _p(kernel), _p(y), n, h, w, c, kh, kw, up, up, down, down, pad[0], pad[1], pad[0], pad[1], _st())
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, pad, (n, h, w, c), (oh, ow))
         return y
@@ -1877,12 +1996,16 @@ class _UpFirDnNHWC(torch.autograd.Function):
         gy1 = h * up - oh * down + pad[0] - up + 1
         gx = torch.empty((n, h, w, c), device=g.device, dtype=g.dtype)
         with _prof(f"bytes:upfirdn2d_bwd|{n}x{h}x{w}x{c} up{up} down{down}", float(g.element_size()) * (g.numel() + gx.numel())):
-            (_L().upfirdn2d_nhwc_bf16 if g.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
-        return gx, None, None, None, None
+            if ctx.sep:
+                _L().blur_act_bf16(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, gx0, gx1, gy0, gy1, None, None, None, None, 1.0, 1.0, 1, _st())
+            else:
+                (_L().upfirdn2d_nhwc_bf16 if g.dtype == BF16 else _L().upfirdn2d_nhwc_f32)(_p(g.contiguous()), _p(gk), _p(gx), n, oh, ow, c, kh, kw, down, down, up, up, gx0, gx1, gy0, gy1, _st())
+        return gx, None, None, None, None, None
 
 
-def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0)):
-    return _UpFirDnNHWC.apply(x, kernel.contiguous(), int(up), int(down), (int(pad[0]), int(pad[1])))
+def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0), separable=False):
+    """separable: the caller states that the taps are an outer product (make_kernel of a 1-D list)"""
+    return _UpFirDnNHWC.apply(x, kernel.contiguous(), int(up), int(down), (int(pad[0]), int(pad[1])), bool(separable))
 
 
 # ---------------------------------------------------------------------------------------------------

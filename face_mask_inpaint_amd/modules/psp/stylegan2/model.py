@@ -11,6 +11,7 @@ go through ONE GEMM.  Public forwards take / return NCHW-shaped tensors; ``nhwc`
 from __future__ import annotations
 
 import math
+import os
 import random
 
 import torch
@@ -56,6 +57,7 @@ class Upsample(nn.Module):
 class Blur(nn.Module):
     def __init__(self, kernel, pad, upsample_factor=1):
         super().__init__()
+        self.separable = torch.as_tensor(kernel).ndim == 1  # make_kernel builds the outer product of a 1-D list
         kernel = make_kernel(kernel)
         if upsample_factor > 1:
             kernel = kernel * (upsample_factor ** 2)
@@ -63,7 +65,7 @@ class Blur(nn.Module):
         self.pad = pad
 
     def nhwc(self, x):
-        return FF.upfirdn2d_nhwc(x, self.kernel, pad=self.pad)
+        return FF.upfirdn2d_nhwc(x, self.kernel, pad=self.pad, separable=self.separable)
 
     def forward(self, input):
         return upfirdn2d(input, self.kernel, pad=self.pad)
@@ -139,6 +141,38 @@ class ModulatedConv2d(nn.Module):
             raise NotImplementedError
         return out
 
+    def nhwc_styled(self, x, style, noise, nw, bias, slope, gain):
+        """the whole StyledConv on bf16 activations with its output stage fused (model.py:241-294 in two launches + one scaling pass):
+        up-convolution -> [Blur + demodulation + noise + bias + leaky ReLU], or [convolution + the same output stage]; None where the
+        fused kernels do not take the shape.  noise: [N,1,H',W'] or None (drawn here, NoiseInjection's default)"""
+        if x.dtype != torch.bfloat16 or not self.demodulate:
+            return None
+        w = self.weight[0]
+        k = self.kernel_size
+        n, h, wd, _ = x.shape
+        if self.upsample:
+            if not (self.blur.separable and self.out_channel % 32 == 0 and tuple(self.blur.kernel.shape) == (4, 4)):
+                return None
+            (pw,) = FF.prepare_weights([(w.transpose(0, 1).contiguous(), None, None, False)])
+            oh, ow = 2 * h, 2 * wd
+        else:
+            (pw,) = FF.prepare_weights([(w, None, None, False)])
+            if not FF.styled_conv_fused_ok(x, pw, self.padding):
+                return None
+            oh, ow = h, wd
+        if noise is None:
+            noise = torch.randn((n, oh, ow), device=x.device)
+        else:
+            noise = noise.expand(n, 1, oh, ow).reshape(n, oh, ow).contiguous()
+        s = FF._Scale.apply(self.modulation(style), float(self.scale))  # scale * s[n, i]
+        xs = FF.scale_channels(x, s)
+        wsq = FF.sqsum_last(w.reshape(self.out_channel * self.in_channel, k * k)).view(self.out_channel, self.in_channel)
+        d = FF.rsqrt_eps(FF.linear(FF.mul(s, s), wsq), 1e-8)  # rsqrt(sum_i s^2 sum_k W^2 + 1e-8)  [N, O]
+        if self.upsample:
+            u = FF.conv_transpose2d(xs, pw, None, None, stride=2, pad=0, out_pad=0)
+            return FF.blur_act(u, self.blur.kernel, self.blur.pad, d, noise, nw, bias, slope, gain)
+        return FF.styled_conv(xs, pw, d, noise, nw, bias, slope, gain, self.padding)
+
     def forward(self, input, style):
         return FF.to_nchw(self.nhwc(FF.to_nhwc(input), style))
 
@@ -166,6 +200,9 @@ class ConstantInput(nn.Module):
         return self.input.repeat(input.shape[0], 1, 1, 1)
 
 
+FUSE_STYLED = os.environ.get("FMI_FUSE_STYLED", "1") != "0"  # bf16 decoder: StyledConv output stages fused into the convolution / the Blur (off: the separate passes)
+
+
 class StyledConv(nn.Module):
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1], demodulate=True):
         super().__init__()
@@ -175,6 +212,10 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def nhwc(self, x, style, noise=None):
+        if x.dtype == torch.bfloat16 and FUSE_STYLED:
+            out = self.conv.nhwc_styled(x, style, noise, self.noise.weight, self.activate.bias, self.activate.negative_slope, self.activate.scale)
+            if out is not None:
+                return out
         out = self.conv.nhwc(x, style)
         n, h, w, c = out.shape
         if noise is None:

@@ -202,6 +202,12 @@ int fmi_conv2d_thin_input_dgrad_f32(const fmi_conv_desc* d, const float* dy, con
 int fmi_conv2d_bf16_supported(const fmi_conv_desc* d);
 int fmi_conv2d_fwd_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, uint16_t* y, float* ws,
                         int64_t ws_floats, void* stream);
+/* y = lrelu(conv(x, W) * colscale[n][k] + nw[0] * noise[n][oy][ox] + bias[k], slope) * gain in one launch: ModulatedConv2d on pre-scaled
+ * activations + demodulation + NoiseInjection + FusedLeakyReLU (stylegan2/model.py:241-294, op/fused_act.py:30-37).  colscale [N][K],
+ * noise [N][OH][OW], bias [K] may be NULL.  FMI_ERR_UNSUPPORTED where the eight-phase kernel does not apply (needs C % 64 == 0,
+ * K % 4 == 0, K > 64, y 8-byte and colscale / bias 16-byte aligned). */
+int fmi_conv2d_fwd_act_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* wnk, const float* colscale, const float* noise,
+                            const float* nw, const float* bias, float slope, float gain, uint16_t* y, void* stream);
 int fmi_conv2d_dgrad_bf16(const fmi_conv_desc* d, const uint16_t* dy, const uint16_t* wck, const float* colscale, uint16_t* dx, float* ws,
                           int64_t ws_floats, void* stream);
 /* dwf[tap][C][K] (fp32, the layout of fmi_conv2d_wgrad_f32) += sum over pixels x (gathered) * dy; fp32 atomics across the pixel
@@ -239,6 +245,14 @@ int fmi_upfirdn2d_nhwc_bf16(const uint16_t* in, const float* kernel, uint16_t* o
 int fmi_blur_act_bf16(const uint16_t* in, const float* kernel, uint16_t* out, int N, int in_h, int in_w, int C, int pad_x0, int pad_x1,
                       int pad_y0, int pad_y1, const float* colscale, const float* noise, const float* nw, const float* bias, float slope,
                       float gain, int separable, void* stream);
+/* Adjoint of the fused output stage y = lrelu(z * colscale[n][c] + nw[0] * noise[n][p] + bias[c], slope) * gain of fmi_blur_act_bf16 /
+ * fmi_conv2d_fwd_act_bf16 in one pass over g and y ([N][P][C] bf16): t = gradient wrt z (bf16), gd [N][C] = gradient wrt colscale,
+ * gbias [C], gnw [1] (gd / gbias / gnw may be NULL).  z is not needed: gpre * (z d + nw noise + bias) = g y on both branches of the
+ * leaky ReLU.  ws: partial sums, >= N*3*C floats; sums: N*3*C floats (both scratch).  Replaces the autograd chain through
+ * FusedLeakyReLU / NoiseInjection / the demodulation product (op/fused_act.py:40-69, model.py:250-252, 282-294). */
+int fmi_styled_out_bwd_bf16(const uint16_t* g, const uint16_t* y, const float* noise, const float* colscale, const float* nw,
+                            const float* bias, uint16_t* t, float* gd, float* gbias, float* gnw, float* ws, int64_t ws_floats, float* sums,
+                            int N, int64_t P, int C, float slope, float gain, void* stream);
 int fmi_torgb_fwd_bf16(const uint16_t* x, const float* w, const float* s, const float* bias, const float* skip, float* out, int N,
                        int64_t P, int C, void* stream);
 int fmi_torgb_bwd_bf16(const uint16_t* x, const float* w, const float* s, const float* g, uint16_t* gx, float* ws, int64_t ws_floats,

@@ -314,6 +314,55 @@ def test_bf16_generator_tracks_fp32(dev):
     assert not bad, bad
 
 
+def test_bf16_generator_fused_output_stages(dev):
+    """the fused StyledConv paths of the bf16 decoder (convolution + output stage in the eight-phase kernel's epilogue at the 64^2
+    layer of this batch, Blur + output stage in one pass after every up-convolution, one fused adjoint pass each) against the separate
+    passes on the same parameters / styles / noise, and both against the fp32 network within the bounds of the test above"""
+    from face_mask_inpaint_amd import functional as FF
+    from face_mask_inpaint_amd.modules.psp.stylegan2 import model as M
+
+    torch.manual_seed(1)
+    g32 = M.Generator(64, 512, 2).to(dev)
+    g16 = M.Generator(64, 512, 2, compute_dtype=BF).to(dev)
+    g16.load_state_dict(g32.state_dict())
+    with torch.no_grad():  # zero-initialised in the reference: give the noise path something to do
+        for m in list(g32.modules()) + list(g16.modules()):
+            if isinstance(m, M.NoiseInjection):
+                m.weight.fill_(0.3)
+            if isinstance(m, M.FusedLeakyReLU):
+                m.bias.copy_(torch.linspace(-0.2, 0.2, m.bias.numel(), device=dev))
+    lat = torch.randn(8, g32.n_latent, 512, device=dev)
+    res = {}
+    for name, gen, fuse in (("fp32", g32, True), ("fused", g16, True), ("separate", g16, False)):
+        M.FUSE_STYLED = fuse
+        FF.PROFILE = [] if name == "fused" else None
+        try:
+            gen.zero_grad(set_to_none=True)
+            latq = lat.clone().requires_grad_(True)
+            img, _ = gen([latq], input_is_latent=True, randomize_noise=False)
+            (img ** 2).mean().backward()
+            res[name] = (img.detach().clone(), latq.grad.clone(), {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None})
+        finally:
+            M.FUSE_STYLED = True
+            if name == "fused":
+                tags, FF.PROFILE = [t for t, *_ in FF.PROFILE], None
+    # both fused forms ran: four up-convolution Blurs with the output stage, the 64^2 convolution with it, one fused adjoint pass each
+    assert sum(t.startswith("bytes:upfirdn2d|") and t.endswith("+out") for t in tags) == 4, tags
+    assert sum(t.startswith("conv_fwd_bf16|") and t.endswith("+out") for t in tags) == 1, tags
+    assert sum(t.startswith("bytes:noise_bias_act_fused_bwd|") for t in tags) == 5, tags
+    ref_img, ref_gl, ref_gp = res["fp32"]
+    for name in ("fused", "separate"):
+        img, gl, gp = res[name]
+        assert (img - ref_img).abs().max().item() < 4e-2 * ref_img.abs().max().item(), name
+        assert (gl - ref_gl).norm().item() < 6e-2 * ref_gl.norm().item(), name
+        assert set(gp) == set(ref_gp)
+        bad = [(k, (gp[k] - ref_gp[k]).norm().item() / max(ref_gp[k].norm().item(), 1e-30)) for k in gp
+               if (gp[k] - ref_gp[k]).norm().item() > (0.3 if gp[k].numel() == 1 else 6e-2) * ref_gp[k].norm().item() + 1e-9]
+        assert not bad, (name, bad)
+    # the two bf16 evaluations differ by rounding only (one rounding per fused stage instead of three)
+    assert (res["fused"][0] - res["separate"][0]).abs().max().item() < 2e-2 * ref_img.abs().max().item()
+
+
 def test_bf16_irse_body_tracks_fp32(dev):
     """GradualStyleEncoder with opts.encoder_dtype = 'bf16' (bf16 activations in the 24 IR-SE blocks, fp32 accumulate / parameters /
     BatchNorm statistics) against the fp32 encoder on the same weights and inputs, training mode, source + reference pass: W+ codes
