@@ -45,12 +45,24 @@ def summarise(recs, peak=FP32_MFMA_PEAK, only_bf16=False):
         fl, ms = sum(f for _, f, _ in conv), sum(m for _, _, m in conv)
         out["mfma"] = {"launches": len(conv), "algorithmic_tflop": round(fl / 1e12, 3), "kernel_ms": round(ms, 3),
                        "tflops": round(fl / ms / 1e9, 2), "peak_tflops": peak, "utilisation": round(fl / ms / 1e9 / peak, 4)}
+        # the same sum over the launches that carry the work (>= 100 GFLOP each): a launch is bracketed by events in an EAGER step, so
+        # the 4^2 .. 16^2 layers (30-60 us each, mostly the gap to the next launch) weigh on the figure above far beyond their FLOPs
+        big = [(f, m) for _, f, m in conv if f >= 1e11]
+        if big:
+            fl, ms = sum(f for f, _ in big), sum(m for _, m in big)
+            out["mfma"]["large_launches"] = {"launches": len(big), "algorithmic_tflop": round(fl / 1e12, 3), "kernel_ms": round(ms, 3),
+                                             "tflops": round(fl / ms / 1e9, 2), "utilisation": round(fl / ms / 1e9 / peak, 4)}
     for key in ("upfirdn2d", "noise_bias_act"):
         sel = [(f, m) for t, f, m in byt if t.startswith("bytes:" + key)]
         if sel:
             b, ms = sum(f for f, _ in sel), sum(m for _, m in sel)
             out[key] = {"launches": len(sel), "algorithmic_GB": round(b / 1e9, 3), "kernel_ms": round(ms, 3), "GBps": round(b / ms / 1e6, 1),
                         "frac_of_hbm_peak": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            big = [(f, m) for f, m in sel if f >= 64e6]  # launches that move >= 64 MB
+            if big:
+                b, ms = sum(f for f, _ in big), sum(m for _, m in big)
+                out[key]["large_launches"] = {"launches": len(big), "algorithmic_GB": round(b / 1e9, 3), "kernel_ms": round(ms, 3),
+                                              "GBps": round(b / ms / 1e6, 1), "frac_of_hbm_peak": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
     return out
 
 
@@ -213,7 +225,8 @@ def extra_block(dev, steps=4, warmup=2):
         out[key] = {"images_per_s": round(batch * steps / dt32, 2), "ms_per_step": round(dt32 / steps * 1e3, 2),
                     "bf16_encoder_body_variant": {"images_per_s": round(batch * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2)},
                     "modulated_conv_bf16": {"tflops": mf.get("tflops"), "frac_of_bf16_peak": mf.get("utilisation"), "launches": mf.get("launches"),
-                                            "kernel_ms": mf.get("kernel_ms"), "algorithmic_tflop": mf.get("algorithmic_tflop")},
+                                            "kernel_ms": mf.get("kernel_ms"), "algorithmic_tflop": mf.get("algorithmic_tflop"),
+                                            "large_launches_ge_100_gflop": mf.get("large_launches")},
                     "all_conv_bf16_incl_encoder_body": {"tflops": mfa.get("tflops"), "frac_of_bf16_peak": mfa.get("utilisation"), "launches": mfa.get("launches"),
                                                         "kernel_ms": mfa.get("kernel_ms"), "algorithmic_tflop": mfa.get("algorithmic_tflop")},
                     "upfirdn2d_in_decoder": summ.get("upfirdn2d"), "noise_bias_act": summ.get("noise_bias_act"),

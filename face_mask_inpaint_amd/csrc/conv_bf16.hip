@@ -726,6 +726,8 @@ __global__ void __launch_bounds__(T::NT) wgrad_bf16_kernel(WgArgsB a, int tiles_
   }
 }
 
+#include "wgrad_bf16_8ph.h"
+
 /* dwf[tap][C][K] (fp32, the layout of fmi_conv2d_wgrad_f32) += x^T dy; caller zeroes dwf */
 extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dwf, void* stream) {
   int rc = check_desc_b(d);
@@ -742,6 +744,26 @@ extern "C" int fmi_conv2d_wgrad_bf16(const fmi_conv_desc* d, const uint16_t* x, 
   g.kh0 = 0; g.kw0 = 0; g.khstep = 1; g.kwstep = 1; g.kw = d->kw;
   g.dGW = make_fastdiv(g.GW); g.dG = make_fastdiv(g.GH * g.GW); g.dC = make_fastdiv(g.C); g.dntx = make_fastdiv(g.ntx);
   a.Kout = d->K; a.ycs = d->y_cstride; a.Mrows = d->kh * d->kw * d->C; a.P = d->N * d->OH * d->OW;
+  // the eight-phase kernel (wgrad_bf16_8ph.h): 256 x 256 tiles, one workgroup per CU -- for wide layers with a long pixel range
+  {
+    const int mode = bf16_tile_mode();
+    const int64_t tm8 = ceil_div64(a.Mrows, 256), tn8 = ceil_div64(d->K, 256);
+    const bool fits = d->K >= 256 && tn8 * 256 - d->K <= d->K / 8 && tm8 * 256 - a.Mrows <= a.Mrows / 8 && tm8 * tn8 <= 256 && a.P >= 4096 &&
+                      (int64_t)d->kh * d->kw * d->C < (1ll << 30) && (int64_t)d->N * d->H * d->W * d->x_cstride < (1ll << 31);
+    if (fits && !fmi_det() && mode != 1 && mode != 2) {
+      Wg8Args w{};
+      w.x = x; w.dy = dy; w.dwf = dwf; w.g = g;
+      w.Kout = d->K; w.ycs = d->y_cstride; w.Mrows = a.Mrows; w.P = a.P;
+      w.tiles = (int)(tm8 * tn8); w.tiles_n = (int)tn8;
+      int64_t ks = 256 / w.tiles;
+      if (ks > a.P / 1024) ks = a.P / 1024;
+      if (ks < 1) ks = 1;
+      w.kchunk = (int)(ceil_div64(ceil_div64(a.P, ks), 64) * 64);
+      w.ksplit = (int)ceil_div64(a.P, w.kchunk);
+      hipLaunchKernelGGL(wgrad_bf16_8ph_kernel, dim3((unsigned)(w.tiles * w.ksplit)), dim3(512), 0, (hipStream_t)stream, w);
+      return fmi_launch_status();
+    }
+  }
   // the 8-wave 256x256 tile (the kernel takes it: WPP = 2) measured SLOWER here than 128x128 (574 vs 770 TFLOP/s at 512 -> 512, 64^2):
   // one workgroup per CU and a 16-accumulator atomic epilogue per split leave the CU idle between tiles
   const int bn = d->K <= 32 ? 32 : (d->K <= 64 ? 64 : 128);

@@ -116,7 +116,9 @@ def test_conv_bf16_split_reduction(dev, FF, n, c, k, h, stride):
 # (256 x 256 for more than 128 output channels, 512 x 128 below), ragged pixel / channel tiles, one to eighteen reduction tiles (the
 # prologue, the steady state and the drained tail of the DMA ring), the four sub-pixel phases of a stride-2 adjoint with 1 / 2 / 2 / 4 taps
 EIGHT_PHASE_CASES = [(3, 128, 256, 32, 32, 3, 1, 1), (2, 64, 128, 24, 20, 3, 1, 1), (2, 64, 320, 9, 11, 3, 1, 1), (1, 64, 128, 16, 16, 1, 1, 0),
-                     (2, 128, 128, 17, 13, 3, 2, 0), (2, 256, 192, 12, 12, 3, 2, 0), (1, 128, 64, 40, 40, 3, 1, 1), (5, 192, 256, 8, 8, 3, 1, 1)]
+                     (2, 128, 128, 17, 13, 3, 2, 0), (2, 256, 192, 12, 12, 3, 2, 0), (1, 128, 64, 40, 40, 3, 1, 1), (5, 192, 256, 8, 8, 3, 1, 1),
+                     # 1x1 stride 2: three of the adjoint's four sub-pixel phases have no tap (no reduction tile: zeros must be written)
+                     (4, 128, 256, 16, 16, 1, 2, 0)]
 
 
 @pytest.mark.parametrize("n,c,k,h,w,ks,stride,pad", EIGHT_PHASE_CASES)
@@ -156,6 +158,42 @@ def test_conv_bf16_eight_phase_kernel(dev, FF, n, c, k, h, w, ks, stride, pad):
             assert torch.equal(dx, dx2)
     finally:
         lib.debug_bf16_tile(prev)
+
+
+# (n, c, k, h, w, ks, stride, pad): weight gradients that reach the eight-phase kernel (csrc/wgrad_bf16_8ph.h): >= 256 output channels,
+# >= 4096 output pixels; row tiles that end inside a tap block (1152 rows = 4.5 tiles), a ragged last pixel tile, the strided form
+# (the decoder's up-convolutions), one and several pixel splits
+WGRAD8_CASES = [(2, 256, 256, 48, 48, 3, 1, 1), (1, 128, 256, 70, 61, 3, 1, 1), (2, 128, 256, 131, 131, 3, 2, 0), (3, 64, 512, 40, 40, 3, 1, 1),
+                (16, 512, 512, 32, 32, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("n,c,k,h,w,ks,stride,pad", WGRAD8_CASES)
+def test_conv_bf16_wgrad_eight_phase(dev, FF, n, c, k, h, w, ks, stride, pad):
+    from face_mask_inpaint_amd import _lib
+
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(c + k + h)
+    x = bf(torch.randn(n, c, h, w, generator=g))
+    wr = torch.zeros(k, c, ks, ks, requires_grad=True)
+    y_ref = F.conv2d(x.float(), wr, stride=stride, padding=pad)
+    gy = bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy.float())
+    d, oh, ow = FF.conv_desc(n, h, w, c, k, ks, ks, stride, pad, 0)
+    assert n * oh * ow >= 4096
+    xh, gh = x.permute(0, 2, 3, 1).contiguous().to(dev), gy.permute(0, 2, 3, 1).contiguous().to(dev)
+    ref = wr.grad.permute(2, 3, 1, 0).reshape(ks * ks, c, k)
+    tol = dict(rtol=1e-4, atol=1e-5 * ref.abs().max().item() * (n * oh * ow) ** 0.5)
+    res = {}
+    for mode in (0, 2):  # by shape (the eight-phase kernel) / the four-wave kernel
+        prev = lib.debug_bf16_tile(mode)
+        try:
+            dwf = torch.zeros(ks * ks, c, k, device=dev)
+            lib.conv2d_wgrad_bf16(C.byref(d), FF._p(xh), FF._p(gh), FF._p(dwf), FF._st())
+        finally:
+            lib.debug_bf16_tile(prev)
+        torch.testing.assert_close(dwf.cpu(), ref, **tol)
+        res[mode] = dwf
+    torch.testing.assert_close(res[0], res[2], rtol=1e-4, atol=tol["atol"])
 
 
 def test_conv_bf16_rejects_unsupported(dev, FF):
