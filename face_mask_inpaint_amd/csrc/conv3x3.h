@@ -26,6 +26,7 @@ struct C3Args {
 // FL: blocked accumulation (a second accumulator set, flushed every 10 steps = 480 reduction elements), see conv_p3.h
 template <class T, bool W3, bool FL = false>
 __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, BK = 16;
   constexpr int RA = ((BM + 2 + 15) / 16) * 16;  // rows of the A image (multiple of the 16 rows one wave instruction writes)
   constexpr int NIA = RA / 16;                   // wave instructions of an A image
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
     for (int j = 0; j < NLA; ++j) {
       if (j >= na_w) break;
       const bool ok = (unsigned)(ay[j] + ky - 1) < (unsigned)a.H;
-      const float* g = ok ? a.x + abase[j] + aoff : fmi_chunk_zero;
+      const float* g = ok ? a.x + abase[j] + aoff : zchunk;
       glds16(g, sa + (uint32_t)(j * 4096));
     }
 #pragma unroll
@@ -137,9 +138,9 @@ __global__ void __launch_bounds__(256) conv3x3_dma_kernel(C3Args a, ConvEp ep, i
       const float* g;
       if (W3)
         g = boff[j] >= 0 ? (const float*)(a.w3 + (int64_t)(bkx[j] >> 2) * 9 * a.C * a.Nout + (((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) >> 3) * a.Nout * 8 + boff[j])
-                         : fmi_chunk_zero;
+                         : zchunk;
       else
-        g = boff[j] >= 0 ? a.w + ((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) * a.Nout + boff[j] : fmi_chunk_zero;
+        g = boff[j] >= 0 ? a.w + ((int64_t)(a.flip ? 8 - tap : tap) * a.C + c0) * a.Nout + boff[j] : zchunk;
       glds16(g, sb + (uint32_t)(j * 4096));
     }
   };

@@ -147,6 +147,7 @@ struct ConvSetB {
 
 template <class T, int BK, int NST = 2>
 __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvSetB set) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, NT = T::NT;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   if (lid >= set.ph[blockIdx.y].tiles) return;  // whole workgroup
@@ -211,14 +212,14 @@ __global__ void __launch_bounds__(T::NT) conv_bf16_kernel(ConvSetB set) {
     for (int j = 0; j < NLA; ++j) {
       if (BM * CPR % NT != 0 && !na_w) break;
       const void* g = la.chunk(da[j], ta);
-      if (!g) g = fmi_chunk_zero;
+      if (!g) g = zchunk;
       glds16(g, sa + j * NT * 16);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       if (BN * CPR % NT != 0 && !nb_w) break;
       const void* g = lb.chunk(db[j], tb);
-      if (!g) g = fmi_chunk_zero;
+      if (!g) g = zchunk;
       glds16(g, sb + j * NT * 16);
     }
   };
@@ -578,6 +579,7 @@ struct WgArgsB {
 // bytes of one group, so a thread's copies share ONE pixel decode; a transposed read of four pixel rows is 256 contiguous bytes.
 template <class T>
 __global__ void __launch_bounds__(T::NT) wgrad_bf16_kernel(WgArgsB a, int tiles_n) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, BK = 64;
   constexpr int WPP = T::NT / 256;  // waves per 16-pixel block of the tile (8-wave tiles: two, each filling every other row group)
   constexpr int NGA = BM / 32 / WPP, NGB = BN / 32 / WPP;
@@ -659,13 +661,13 @@ __global__ void __launch_bounds__(T::NT) wgrad_bf16_kernel(WgArgsB a, int tiles_
 #pragma unroll
     for (int j = 0; j < NGA; ++j) {
       const bool ok = pv && (unsigned)(iy0 + a_dy[j]) < (unsigned)g.IH && (unsigned)(ix0 + a_dx[j]) < (unsigned)g.IW;
-      const void* gp = ok ? (const void*)(a.x + xb + a_off[j]) : (const void*)fmi_chunk_zero;
+      const void* gp = ok ? (const void*)(a.x + xb + a_off[j]) : (const void*)zchunk;
       glds16(gp, sa + j * WPP * 4096);
     }
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {
       const bool ok = pv && b_col[j] >= 0;
-      const void* gp = ok ? (const void*)(a.dy + (int64_t)pix * a.ycs + b_col[j]) : (const void*)fmi_chunk_zero;
+      const void* gp = ok ? (const void*)(a.dy + (int64_t)pix * a.ycs + b_col[j]) : (const void*)zchunk;
       glds16(gp, sb + j * WPP * 4096);
     }
   };

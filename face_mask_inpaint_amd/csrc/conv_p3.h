@@ -117,6 +117,7 @@ __device__ __forceinline__ void p3_acc_flush(f32x16 (&src)[T::TM][T::TN], f32x16
 // measured on the whole-pSp fixture, the unsplit sequential form is 3 x further from float64 than the reference's own fp32 run.
 template <class T, bool FL = false>
 __global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, ConvEp ep, int M, int N, int K, int tiles_n, int ksplit, int kchunk) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, BK = 16;
   constexpr int NIA = BM * 6 / 64, NIB = BN * 6 / 64;  // wave instructions (1 KiB each) of the A / B image of a stage
   constexpr int NLA = (NIA + 3) / 4, NLB = (NIB + 3) / 4;
@@ -169,14 +170,14 @@ __global__ void __launch_bounds__(256) gemm_p3_kernel(ConvK3 la, ConvWX3 lb, Con
     for (int j = 0; j < NLA; ++j) {
       if (j >= na_w) break;
       const void* g = la.chunk(da[j], ta);
-      if (!g || (FMI_P3_EXP & 1)) g = fmi_chunk_zero;
+      if (!g || (FMI_P3_EXP & 1)) g = zchunk;
       glds16_p3(g, sa + j * 4096);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       if (j >= nb_w) break;
       const void* g = lb.chunk(db[j], tb);
-      if (!g || (FMI_P3_EXP & 2)) g = fmi_chunk_zero;
+      if (!g || (FMI_P3_EXP & 2)) g = zchunk;
       glds16_p3(g, sb + j * 4096);
     }
   };
@@ -306,6 +307,7 @@ struct C3P3Args {
 
 template <class T, bool FL = false>
 __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, ConvEp ep, int M, int tiles_n, int ksplit, int it_chunk) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, NW = T::NW;
   constexpr int NIA = ((BM + 2) * 6 + 63) / 64;  // wave instructions (1 KiB) of the A image
   constexpr int NIB = 18 * BN / 64;              // ... of the three weight tiles
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, Conv
     for (int j = 0; j < NLA; ++j) {
       if (j >= na_w) break;
       const bool ok = (unsigned)(ay[j] + ky - 1) < (unsigned)a.H;
-      const void* g = ok ? (const void*)(a.x3 + abase[j] + aoff) : (const void*)fmi_chunk_zero;
+      const void* g = ok ? (const void*)(a.x3 + abase[j] + aoff) : (const void*)zchunk;
       glds16_p3(g, sa + (uint32_t)(j * NW * 1024));
     }
 #pragma unroll
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(T::NW * 64) conv3x3_p3_kernel(C3P3Args a, Conv
       if (j >= nb_w) break;
       const int tap = ky * 3 + (bkx[j] & 3);
       const void* g = boff[j] >= 0 ? (const void*)(a.w3 + (int64_t)(bkx[j] >> 2) * wpiece + ((int64_t)(a.flip ? 8 - tap : tap) * (a.C >> 3) + cg * 2) * a.Nout * 8 + boff[j])
-                                   : (const void*)fmi_chunk_zero;
+                                   : (const void*)zchunk;
       glds16_p3(g, sb + (uint32_t)(j * NW * 1024));
     }
   };
@@ -515,6 +517,7 @@ struct WgP3Args {
 
 template <class T, bool FL = false>
 __global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int tiles_n) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = T::BM, BN = T::BN, BK = 16, NW = T::NW;
   constexpr int GA = BM / 32, GB = BN / 32;       // 32-row groups per operand tile
   constexpr int NI = 3 * (GA + GB);               // wave instructions per stage
@@ -595,10 +598,10 @@ __global__ void __launch_bounds__(T::NW * 64) wgrad_p3_kernel(WgP3Args a, int ti
       if (j >= n_w) break;
       const void* gp;
       if (s_dy[j] == 0x40000000) {
-        gp = pv ? (const void*)(a.dy3 + yb + s_off[j]) : (const void*)fmi_chunk_zero;
+        gp = pv ? (const void*)(a.dy3 + yb + s_off[j]) : (const void*)zchunk;
       } else {
         const bool ok = pv && (unsigned)(iy0 + s_dy[j]) < (unsigned)g.IH && (unsigned)(ix0 + s_dx[j]) < (unsigned)g.IW;
-        gp = ok ? (const void*)(a.x3 + xb + s_off[j]) : (const void*)fmi_chunk_zero;
+        gp = ok ? (const void*)(a.x3 + xb + s_off[j]) : (const void*)zchunk;
       }
       glds16_p3(gp, s0 + (uint32_t)(j * NW * 1024));
     }
@@ -694,6 +697,7 @@ struct Wg3x3Args {
 
 template <int GA, int TN, bool FL = false>
 __global__ void __launch_bounds__(256, FL ? 1 : 2) wgrad3x3_p3_kernel(Wg3x3Args a, int tiles_n) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int NW = 4, WN = 4 / GA, BN = WN * TN * 32, GB = BN / 32, BK = 16;
   constexpr int NIA = 3 * GA, NIB = 3 * GB, NI = NIA + NIB + 1;  // main A images, B images, one halo instruction
   constexpr int NL = (NI + NW - 1) / NW;
@@ -794,7 +798,7 @@ __global__ void __launch_bounds__(256, FL ? 1 : 2) wgrad3x3_p3_kernel(Wg3x3Args 
       if (j >= n_w) break;
       const int pix = s_halo[j] ? ph : pm;
       const bool ok = s_on[j] && (s_halo[j] ? vh : vm) && (!s_row[j] || (s_halo[j] ? rh : rm));
-      const void* gp = ok ? (const void*)(s_base[j] + (int64_t)pix * s_pitch[j] + s_off[j]) : (const void*)fmi_chunk_zero;
+      const void* gp = ok ? (const void*)(s_base[j] + (int64_t)pix * s_pitch[j] + s_off[j]) : (const void*)zchunk;
       glds16_p3(gp, s0 + s_dst[j]);
     }
   };

@@ -40,6 +40,7 @@ __device__ __forceinline__ int ct3_tap(int dy, int slot) {
 
 template <int TN>
 __global__ void __launch_bounds__(256, TN == 1 ? 3 : 2) convt3x3s2_dma_kernel(CT3Args a, int M, int tiles_n) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   constexpr int BM = 128, BN = 32 * TN, BK = 16;
   constexpr int RA = ((BM + 1 + 15) / 16) * 16;  // 144 rows
   constexpr int NIA = RA / 16;                   // 9 wave instructions of an A image
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(256, TN == 1 ? 3 : 2) convt3x3s2_dma_kernel(CT
     for (int j = 0; j < NLA; ++j) {
       if (j >= na_w) break;
       const bool ok = ay[j] + dy < a.H;
-      const void* g = ok ? (const void*)(xs + (second ? abase2[j] : abase[j]) + aoff) : (const void*)fmi_chunk_zero;
+      const void* g = ok ? (const void*)(xs + (second ? abase2[j] : abase[j]) + aoff) : (const void*)zchunk;
       glds16(g, sa + (uint32_t)(j * 4096));
     }
     const int ntap = dy ? 3 : 6;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256, TN == 1 ? 3 : 2) convt3x3s2_dma_kernel(CT
       const int tap = ct3_tap(dy, slot);
       const void* g = (boff[j] >= 0 && slot < ntap)
                           ? (const void*)(ws + (int64_t)(bslot[j] >> 3) * wpiece + (((int64_t)tap * cred + c0) >> 3) * a.Nout * 8 + boff[j])
-                          : (const void*)fmi_chunk_zero;
+                          : (const void*)zchunk;
       glds16(g, sb + (uint32_t)(j * 4096));
     }
   };

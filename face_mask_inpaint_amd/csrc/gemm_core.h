@@ -620,6 +620,16 @@ __device__ __forceinline__ void store_tile(const EP& ep, f32x16 (&acc)[T::TM][T:
 
 // constant 16-byte chunks the LDS-DMA path reads for out-of-range / synthetic operand elements
 static __device__ __attribute__((aligned(16))) float fmi_chunk_zero[4] = {0.f, 0.f, 0.f, 0.f};
+// A kernel takes the address of the zero chunk ONCE, pinned in scalar registers: written `cond ? p : fmi_chunk_zero` inside a copy loop,
+// every use became s_getpc + s_load_dwordx2 from the GOT + s_waitcnt lgkmcnt(0) -- five scalar-memory round trips per reduction tile in
+// the issue section of conv3x3_p3_kernel, and (the counter is shared) a wait for every LDS read in flight wherever reads precede it.
+__device__ __forceinline__ const float* fmi_zero_chunk_ptr() {
+  const float* p = fmi_chunk_zero;
+#ifndef FMI_ZCHUNK_NOPIN  // A/B build: the address re-materialised at every use, as before
+  asm volatile("" : "+s"(p));
+#endif
+  return p;
+}
 static __device__ __attribute__((aligned(16))) float fmi_chunk_one[4] = {1.f, 0.f, 0.f, 0.f};
 
 __device__ __forceinline__ const float* WgradAX::chunk(const DCtx& d, const Tile&) const {
@@ -866,6 +876,7 @@ struct is_split3<L, std::void_t<decltype(L::SPLIT3)>> : std::integral_constant<b
 template <class LA, class LB, class EP, class T, bool FL = false>
 __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, LB lb, EP ep, int M, int N, int K, int tiles_n,
                                                            int ksplit, int kchunk) {
+  const float* const zchunk = fmi_zero_chunk_ptr();  // the zero chunk's address: read from the GOT ONCE (see fmi_zero_chunk_ptr)
   #ifndef FMI_NST
 #define FMI_NST 2
 #endif
@@ -960,7 +971,7 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
     for (int j = 0; j < NLA; ++j) {
       if (BM % 64 != 0 && !na_w) break;
       const float* g = la.chunk(da[j], ta);
-      if (!g) g = fmi_chunk_zero;
+      if (!g) g = zchunk;
       glds16(g, sa + j * 4096);
       la.advance(da[j]);
     }
@@ -969,12 +980,12 @@ __global__ void __launch_bounds__(256) FMI_DMA_ATTR gemm_dma_f32_kernel(LA la, L
       if constexpr (B3) {
         if (j >= nb_w) break;
         const void* g = lb.chunk(db[j], tb);
-        if (!g) g = fmi_chunk_zero;
+        if (!g) g = zchunk;
         glds16((const float*)g, sb + j * 4096);
       } else {
         if (BN % 64 != 0 && !nb_w) break;
         const float* g = lb.chunk(db[j], tb);
-        if (!g) g = fmi_chunk_zero;
+        if (!g) g = zchunk;
         glds16(g, sb + j * 4096);
         lb.advance(db[j]);
       }
