@@ -341,6 +341,22 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
     return;
   }
   const float nwv = (act.on && act.noise) ? act.nw[0] : 0.f;
+  // a plain stride-1 convolution writes anchor row r to pixel r: no decode of (sample, y, x) per row -- eight of them per lane were a
+  // quarter of this stage's instructions; the sample index is only needed for the per-sample column scale
+  const bool linear = ep.OS == 1 && ep.GH == ep.OHt && ep.GW == ep.OWt;
+  // the lane's four column groups are the same for all of its eight rows: bias once, the per-sample column scale once per sample
+  // (a tile straddles a sample boundary at most once) -- reloaded per (row, group) they were 64 loads per lane
+  float4 bsv[2][2], csv[2][2];
+  int n_cached = -1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = n0 + wc * 64 + j * 32 + c * 16 + cl;
+      bsv[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      csv[j][c] = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (act.on && act.bias && col < N) bsv[j][c] = *reinterpret_cast<const float4*>(act.bias + col);
+    }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -348,7 +364,24 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
       const int row = m0 + wr * 128 + i * 64 + r * 16 + l15;
       if (row >= M) continue;
       int n_s = 0;
-      const int64_t pix = ep.row_pix(row, n_s), off = pix * ep.cstride;
+      int64_t pix;
+      if (linear) {
+        pix = row;
+        if (ep.colscale) n_s = (int)fdiv((uint32_t)row, ep.dG);
+      } else {
+        pix = ep.row_pix(row, n_s);
+      }
+      const int64_t off = pix * ep.cstride;
+      if (ep.colscale && n_s != n_cached) {
+        n_cached = n_s;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int col = n0 + wc * 64 + j * 32 + c * 16 + cl;
+            if (col < N) csv[j][c] = *reinterpret_cast<const float4*>(ep.colscale + (int64_t)n_s * ep.Nout + col);
+          }
+      }
       float nz = 0.f;
       if (act.on && act.noise) nz = nwv * act.noise[pix];
 #pragma unroll
@@ -358,14 +391,9 @@ __global__ void __launch_bounds__(512) conv_bf16_8ph_kernel(ConvSetB set, EpActB
           const int col = n0 + wc * 64 + j * 32 + c * 16 + cl;
           if (col >= N) continue;
           f32x4v a = acc[i][j][r][c];
-          if (ep.colscale) {
-            const float4 cs = *reinterpret_cast<const float4*>(ep.colscale + (int64_t)n_s * ep.Nout + col);
-            a[0] *= cs.x, a[1] *= cs.y, a[2] *= cs.z, a[3] *= cs.w;
-          }
+          if (ep.colscale) a[0] *= csv[j][c].x, a[1] *= csv[j][c].y, a[2] *= csv[j][c].z, a[3] *= csv[j][c].w;
           if (act.on) {
-            float4 b = {0.f, 0.f, 0.f, 0.f};
-            if (act.bias) b = *reinterpret_cast<const float4*>(act.bias + col);
-            const float bb[4] = {b.x, b.y, b.z, b.w};
+            const float bb[4] = {bsv[j][c].x, bsv[j][c].y, bsv[j][c].z, bsv[j][c].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float v = a[e] + nz + bb[e];
