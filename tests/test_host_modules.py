@@ -168,6 +168,27 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert c.fmi_ssim_valid_f32(p, p, p, 11, 1, 8, 8, 1e-4, 9e-4, p, p, 128, None) == BAD                      # image smaller than the window
     c.fmi_adam_step_dev_guarded_f32.argtypes = [vp, ctypes.c_int] + [f32] * 5 + [vp, vp, vp]
     assert c.fmi_adam_step_dev_guarded_f32(None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, p, p, None) == BAD
+    # fused StyledConv entries of the bf16 decoder (round 3)
+    ci = ctypes.c_int
+    c.fmi_blur_act_bf16.argtypes = [vp, vp, vp] + [ci] * 8 + [vp, vp, vp, vp, f32, f32, ci, vp]
+    assert c.fmi_blur_act_bf16(None, p, p, 1, 9, 9, 64, 1, 1, 1, 1, None, None, None, None, 0.2, 1.4, 1, None) == BAD     # in = NULL
+    assert c.fmi_blur_act_bf16(p, p, p, 1, 9, 9, 64, 1, 1, 1, 1, None, p, None, None, 0.2, 1.4, 1, None) == BAD        # noise without its weight
+    assert c.fmi_blur_act_bf16(p, p, p, 1, 2, 2, 64, 0, 0, 0, 0, None, None, None, None, 1.0, 1.0, 1, None) == BAD     # 2 x 2 input: no output pixel
+    assert c.fmi_blur_act_bf16(p, p, p, 1, 9, 9, 24, 1, 1, 1, 1, None, None, None, None, 1.0, 1.0, 1, None) == UNSUP   # channels % 32 != 0
+    assert c.fmi_blur_act_bf16(p, p, p, 1, 9, 9, 64, 1, 1, 1, 1, None, None, None, p, 0.2, 1.4, 0, None) == UNSUP      # output stage needs rank-one taps
+    c.fmi_styled_out_bwd_bf16.argtypes = [vp] * 11 + [i64, vp, ci, i64, ci, f32, f32, vp]
+    assert c.fmi_styled_out_bwd_bf16(p, p, None, None, None, None, p, None, None, None, p, 16, p, 1, 4, 64, 0.2, 1.4, None) == BAD   # workspace < N*3*C
+    assert c.fmi_styled_out_bwd_bf16(p, p, p, None, None, None, p, None, None, None, p, 4096, p, 1, 4, 64, 0.2, 1.4, None) == BAD   # noise without its weight
+    assert c.fmi_styled_out_bwd_bf16(p, p, None, None, None, None, p, None, None, None, p, 4096, p, 1, 4, 12, 0.2, 1.4, None) == UNSUP  # channels % 8 != 0
+    db = _lib.ConvDesc(N=1, H=8, W=8, C=64, OH=8, OW=8, K=128, x_cstride=64, y_cstride=128, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    c.fmi_conv2d_fwd_act_bf16.argtypes = [ctypes.POINTER(_lib.ConvDesc), vp, vp, vp, vp, vp, vp, f32, f32, vp, vp]
+    assert c.fmi_conv2d_fwd_act_bf16(ctypes.byref(db), p, p, None, p, None, None, 0.2, 1.4, p, None) == BAD             # noise without its weight
+    assert c.fmi_conv2d_fwd_act_bf16(ctypes.byref(db), None, p, None, None, None, None, 0.2, 1.4, p, None) == BAD       # x = NULL
+    db32 = _lib.ConvDesc(N=1, H=8, W=8, C=32, OH=8, OW=8, K=128, x_cstride=32, y_cstride=128, kh=3, kw=3, stride=1, pad=1, pad_mode=0)
+    assert c.fmi_conv2d_fwd_act_bf16(ctypes.byref(db32), p, p, None, None, None, None, 0.2, 1.4, p, None) == UNSUP      # 32 input channels: no eight-phase kernel
+    c.fmi_debug_bf16_tile.argtypes = [ci]
+    prev = c.fmi_debug_bf16_tile(-1)                                                                                 # query only
+    assert c.fmi_debug_bf16_tile(8) == prev and c.fmi_debug_bf16_tile(prev) == 8 and c.fmi_debug_bf16_tile(-1) == prev
 
 
 def test_pmc_traffic_profile_is_current():
