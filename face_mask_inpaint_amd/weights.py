@@ -10,6 +10,7 @@ base_function.py:441-446) are excluded so that their u/v stay untouched.
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -18,6 +19,7 @@ from torch import nn
 from . import functional as FF
 
 _ACTIVE = [0]
+KEEP_FROZEN_PACKS = os.environ.get("FMI_FROZEN_PACKS", "1") != "0"  # off: every weight is re-packed every forward (A/B)
 
 
 def _collect(root: nn.Module, skip=()) -> List[nn.Module]:
@@ -62,21 +64,43 @@ class weight_scope:
             self.owner = True
             convs = _collect(self.root, self.skip)
             if convs:
-                items = []
+                items, todo = [], []
                 for c in convs:
                     w3 = not getattr(c, "_fmi_no_w3", False)  # set on convolutions that run on bf16 activations
                     if hasattr(c, "weight_bar"):
                         items.append((c.weight_bar, c.weight_u, c.weight_v, w3, getattr(c, "_fmi_power_iterations", 1)))
-                    else:
-                        items.append((c.weight, None, None, w3))
-                for c, pw in zip(convs, FF.prepare_weights(items)):
-                    object.__setattr__(c, "_fmi_packed", pw)
+                        todo.append((c, None))
+                        continue
+                    # A FROZEN weight (the loss networks of train_psp.py: ArcFace IR-SE50, VGG19, AlexNet; every network at inference) is
+                    # packed once and the packs are kept while the tensor is unchanged -- same storage, same version counter, same
+                    # want_w3.  Trainable weights are re-packed every forward: the fused optimiser writes them through raw pointers,
+                    # which the version counter does not see.  (In-place edits through ``.data`` bypass the counter as well:
+                    # ``invalidate_packs(module)`` after such an edit.)
+                    w = c.weight
+                    key = None if (w.requires_grad or not KEEP_FROZEN_PACKS) else (w.data_ptr(), w._version, tuple(w.shape), w3)
+                    cached = getattr(c, "_fmi_frozen_pack", None)
+                    if key is not None and cached is not None and cached[0] == key:
+                        object.__setattr__(c, "_fmi_packed", cached[1])
+                        continue
+                    items.append((w, None, None, w3))
+                    todo.append((c, key))
+                if items:
+                    for (c, key), pw in zip(todo, FF.prepare_weights(items)):
+                        object.__setattr__(c, "_fmi_packed", pw)
+                        object.__setattr__(c, "_fmi_frozen_pack", None if key is None else (key, pw))
         _ACTIVE[0] += 1
         return self
 
     def __exit__(self, *exc):
         _ACTIVE[0] -= 1
         return False
+
+
+def invalidate_packs(root: nn.Module) -> None:
+    """forget the kept packs of frozen weights under ``root`` (needed only after edits that bypass the tensor's version counter)"""
+    for m in root.modules():
+        if hasattr(m, "_fmi_frozen_pack"):
+            object.__setattr__(m, "_fmi_frozen_pack", None)
 
 
 def packed(conv: nn.Module) -> FF.PackedWeight:
