@@ -2177,10 +2177,42 @@ def split_batch(x, n):
     return _SplitBatch.apply(x, int(n))
 
 
+class _ChannelAffineFrozen(torch.autograd.Function):
+    """y[..., c] = x * scale[c] + shift[c] with CONSTANT scale / shift (a frozen eval-mode BatchNorm) in one pass each way: the
+    normalisation kernel with mean 0 / rstd 1 statistics forward, the channel scaling backward"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, unit):
+        _chk(x, scale, shift, unit)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _L().instnorm_apply_f32(_p(x), _p(unit), _p(scale), _p(shift), _p(y), 1, x.numel() // c, c, 1.0, _st())
+        ctx.save_for_backward(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        g = g.contiguous()
+        c = g.shape[-1]
+        gx = torch.empty_like(g)
+        _L().scale_channels_f32(_p(g), _p(scale), _p(gx), 1, g.numel() // c, c, _st())
+        return gx, None, None, None
+
+
+_UNIT_STATS = {}
+
+
 def channel_affine(x, scale, shift):
     """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); gradients reach scale / shift when they require them"""
     n = x.shape[0]
     c = x.shape[-1]
+    if x.dtype == torch.float32 and not scale.requires_grad and not shift.requires_grad and x.is_cuda:
+        unit = _UNIT_STATS.get((x.device, c))
+        if unit is None:  # stats[1][C][2] = (mean 0, rstd 1)
+            unit = torch.tensor([0.0, 1.0], device=x.device).repeat(c).view(1, c, 2).contiguous()
+            _UNIT_STATS[(x.device, c)] = unit
+        return _ChannelAffineFrozen.apply(x.contiguous(), scale.contiguous(), shift.contiguous(), unit)
     y = scale_channels(x.reshape(1, -1, c), scale.view(1, c).contiguous())
     return _BiasAdd.apply(y.view(x.shape), shift.contiguous())
 

@@ -75,9 +75,23 @@ def batch_norm(bn: BatchNorm2d, x, passthrough=False):
     # eval mode: frozen statistics, but the affine parameters still receive gradients like torch.nn.BatchNorm2d's do
     # ([C]-sized torch bookkeeping; the per-pixel work and its reductions are the library's)
     want = torch.is_grad_enabled() and (bn.weight.requires_grad or bn.bias.requires_grad)
-    with torch.enable_grad() if want else torch.no_grad():
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        shift = bn.bias - bn.running_mean * scale
+    if not want:
+        # frozen statistics AND frozen affine parameters (ArcFace inside IDLoss: ~50 BatchNorms, two forwards per step): scale / shift
+        # are constants -- five [C]-sized launches per BatchNorm and forward otherwise.  Kept while none of the four tensors changes
+        # (storage + version counter, as weights.weight_scope keeps the packs of frozen convolution weights).
+        key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_var, bn.running_mean)) + (bn.eps,)
+        kept = getattr(bn, "_fmi_affine", None)
+        if kept is not None and kept[0] == key:
+            scale, shift = kept[1], kept[2]
+        else:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                shift = bn.bias - bn.running_mean * scale
+            object.__setattr__(bn, "_fmi_affine", (key, scale, shift))
+    else:
+        with torch.enable_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
     y = FF.channel_affine(x, scale, shift)
     return (y, x) if passthrough else y
 

@@ -12,8 +12,9 @@ opts = types.SimpleNamespace(output_size=256, encoder_type="GradualStyleEncoder"
                              stylegan_weights=None, learn_in_w=False, start_from_latent_avg=True, decoder_dtype="bf16")
 net = pSp(opts).to(dev).train()
 net.latent_avg = torch.zeros(opts.n_styles, 512, device=dev)
-crit = pSpLoss(types.SimpleNamespace(id_lambda=0, lpips_lambda=0, l2_lambda=1.0, style_lambda=0, lpips_lambda_ref=0, l2_lambda_ref=1.0, cx_lambda=0,
-                                     w_norm_lambda=0.005, start_from_latent_avg=True))
+crit = pSpLoss(types.SimpleNamespace(**(B.SCRIPT_LOSS_ARGS if "script" in sys.argv else B.LOSS_ARGS)))
+if hasattr(crit, "to"):
+    crit = crit.to(dev)
 opt = FusedAdam([p for p in net.encoder.parameters() if p.requires_grad], lr=1e-4)
 x, ref, y, m = B.synth(16, dev)
 def step():
