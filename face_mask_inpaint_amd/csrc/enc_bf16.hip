@@ -218,6 +218,28 @@ extern "C" int fmi_add_bcast_bf16(const uint16_t* g, const float* gpool, uint16_
   return fmi_launch_status();
 }
 
+// fp32 twin (the fp32 IR-SE50 body of configs C3 / C5): the SE input's two gradients -- through the gated product and through the
+// global average pool -- meet in one pass instead of a pool-backward pass plus an accumulation pass of the autograd engine
+__global__ void __launch_bounds__(256) add_bcast_f32_kernel(const float4* __restrict__ g, const float* __restrict__ gpool, float4* __restrict__ gx,
+                                                            int64_t PC4, int C4, int64_t total, float inv) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t n = i / PC4;
+    float4 v = g[i];
+    const float4 p = *reinterpret_cast<const float4*>(gpool + (n * C4 + c4) * 4);
+    v.x += p.x * inv, v.y += p.y * inv, v.z += p.z * inv, v.w += p.w * inv;
+    gx[i] = v;
+  }
+}
+extern "C" int fmi_add_bcast_f32(const float* g, const float* gpool, float* gx, int N, int64_t P, int C, void* stream) {
+  if (!g || !gpool || !gx || N <= 0 || P <= 0 || C <= 0) return FMI_ERR_BAD_ARG;
+  if (C % 4 != 0 || !e_al16(g) || !e_al16(gx) || !e_al16(gpool)) return FMI_ERR_UNSUPPORTED;
+  const int64_t total = (int64_t)N * P * (C / 4);
+  hipLaunchKernelGGL(add_bcast_f32_kernel, dim3(fmi_bw_grid(total, 256 * 2)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, gpool, (float4*)gx,
+                     P * (C / 4), C / 4, total, 1.f / (float)P);
+  return fmi_launch_status();
+}
+
 // ---- MaxPool2d(1, stride): y[n][oy][ox] = x[n][oy s][ox s]; backward scatters into zeros --------------------------------------
 __global__ void __launch_bounds__(256) subsample_bf16_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int H, int W, int C8, int OH, int OW,
                                                              int s, int64_t total, int backward) {

@@ -1848,6 +1848,32 @@ def global_avg_pool_pass_bf16(x):
     return _GlobalAvgPoolPassBF16.apply(x.contiguous())
 
 
+class _GlobalAvgPoolPassF32(torch.autograd.Function):
+    """fp32 twin of _GlobalAvgPoolPassBF16: AdaptiveAvgPool2d(1) of a square NHWC map -> (pooled [N,1,1,C], x'), x' being x for its
+    other consumer; backward: gx = g_x' + g_pooled[n][c] / (H W) in one pass (fmi_add_bcast_f32)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, 1, 1, c), device=x.device, dtype=torch.float32)
+        _L().avgpool_f32(_p(x), _p(y), n, h, w, c, h, _st())
+        ctx.shape = x.shape
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gp, gx_pass):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, device=gp.device, dtype=torch.float32)
+        _L().add_bcast_f32(_p(gx_pass.contiguous()), _p(gp.contiguous()), _p(gx), n, h * w, c, _st())
+        return gx
+
+
+def global_avg_pool_pass(x):
+    """(pooled [N,1,1,C], x') for a square fp32 NHWC map with C % 4 == 0; see _GlobalAvgPoolPassF32"""
+    return _GlobalAvgPoolPassF32.apply(x.contiguous())
+
+
 class _SqSumLast(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -2200,11 +2226,39 @@ class _ChannelAffineFrozen(torch.autograd.Function):
         return gx, None, None, None
 
 
+class _ChannelAffineFrozenPass(torch.autograd.Function):
+    """_ChannelAffineFrozen that also hands x on to its OTHER consumer (the identity shortcut of an IR block): (y, x'); the gradient
+    coming back through x' is added inside the backward pass, gx = g * scale + g_x' (fmi_scale_channels_add_f32), instead of by an
+    accumulation pass of the autograd engine"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, unit):
+        _chk(x, scale, shift, unit)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        _L().instnorm_apply_f32(_p(x), _p(unit), _p(scale), _p(shift), _p(y), 1, x.numel() // c, c, 1.0, _st())
+        ctx.save_for_backward(scale)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, gpass):
+        (scale,) = ctx.saved_tensors
+        g = g.contiguous()
+        c = g.shape[-1]
+        gx = torch.empty_like(g)
+        if gpass is None:
+            _L().scale_channels_f32(_p(g), _p(scale), _p(gx), 1, g.numel() // c, c, _st())
+        else:
+            _L().scale_channels_add_f32(_p(g), _p(scale), _p(gpass.contiguous()), _p(gx), 1, g.numel() // c, c, _st())
+        return gx, None, None, None
+
+
 _UNIT_STATS = {}
 
 
-def channel_affine(x, scale, shift):
-    """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); gradients reach scale / shift when they require them"""
+def channel_affine(x, scale, shift, passthrough=False):
+    """y[..., c] = x * scale[c] + shift[c]  (BatchNorm2d in eval mode); gradients reach scale / shift when they require them.
+    passthrough (constant scale / shift only): returns (y, x') -- see _ChannelAffineFrozenPass; None where that form does not apply"""
     n = x.shape[0]
     c = x.shape[-1]
     if x.dtype == torch.float32 and not scale.requires_grad and not shift.requires_grad and x.is_cuda:
@@ -2212,7 +2266,11 @@ def channel_affine(x, scale, shift):
         if unit is None:  # stats[1][C][2] = (mean 0, rstd 1)
             unit = torch.tensor([0.0, 1.0], device=x.device).repeat(c).view(1, c, 2).contiguous()
             _UNIT_STATS[(x.device, c)] = unit
+        if passthrough:
+            return _ChannelAffineFrozenPass.apply(x.contiguous(), scale.contiguous(), shift.contiguous(), unit)
         return _ChannelAffineFrozen.apply(x.contiguous(), scale.contiguous(), shift.contiguous(), unit)
+    if passthrough:
+        return None
     y = scale_channels(x.reshape(1, -1, c), scale.view(1, c).contiguous())
     return _BiasAdd.apply(y.view(x.shape), shift.contiguous())
 

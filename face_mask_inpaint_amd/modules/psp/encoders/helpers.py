@@ -39,6 +39,7 @@ def get_blocks(num_layers):
 # its body on the source and then on the reference image): training-mode BatchNorm then normalises and updates per part, in order
 BN_GROUPS = [1]
 _FUSE = __import__("os").environ.get("FMI_IRSE_FUSE_OFF") is None  # debug: A/B of the block-level fusions below
+_GATE_PASS = __import__("os").environ.get("FMI_IRSE_GATE_PASS", "1") != "0"  # debug: A/B of the SE input's one-pass gradient join (fp32)
 
 
 def batch_norm(bn: BatchNorm2d, x, passthrough=False):
@@ -92,6 +93,10 @@ def batch_norm(bn: BatchNorm2d, x, passthrough=False):
         with torch.enable_grad():
             scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
             shift = bn.bias - bn.running_mean * scale
+    if passthrough and _GATE_PASS and __import__("os").environ.get("FMI_IRSE_GATE_PASS", "1") != "2":  # frozen network: the other consumer's gradient joins inside this op's backward pass
+        yp = FF.channel_affine(x, scale, shift, passthrough=True)
+        if yp is not None:
+            return yp
     y = FF.channel_affine(x, scale, shift)
     return (y, x) if passthrough else y
 
@@ -111,6 +116,16 @@ class SEModule(Module):
         s = FF.avg_pool(x, h) if h == w else FF.adaptive_avg_pool(x, 1, 1)  # AdaptiveAvgPool2d(1) -> [N,1,1,C]
         s = FF.leaky_relu(run_conv(self.fc1, s), 0.0)
         return FF.sigmoid(run_conv(self.fc2, s)).view(n, c)
+
+    def gate_pass(self, x):
+        """fp32 activations: (gates [N, C], x') -- x' is x handed on to the gated product, so that x's two gradients meet in one kernel
+        instead of a pool-backward pass plus an accumulation pass (functional._GlobalAvgPoolPassF32); None where that op does not apply"""
+        n, h, w, c = x.shape
+        if not _GATE_PASS or h != w or c % 4 != 0 or x.dtype != torch.float32:
+            return None
+        pooled, xp = FF.global_avg_pool_pass(x)
+        s = FF.leaky_relu(run_conv(self.fc1, pooled), 0.0)
+        return FF.sigmoid(run_conv(self.fc2, s)).view(n, c), xp
 
     def gate_bf16(self, x):
         """bf16 activations: (gates fp32 [N, C], x') -- x' is x handed on to the gated product so that both gradients of x meet in
@@ -147,6 +162,9 @@ class _Bottleneck(Module):
                 gates, rp = self.res_layer[5].gate_bf16(r)
                 return FF.scale_channels_add(rp, gates, sc)
             if len(self.res_layer) > 5 and _FUSE:  # SE gate and residual add in one pass
+                gp = self.res_layer[5].gate_pass(r)
+                if gp is not None:
+                    return FF.scale_channels_add(gp[1], gp[0], sc)
                 return FF.scale_channels_add(r, self.res_layer[5].gate(r), sc)
             if len(self.res_layer) > 5:
                 r = self.res_layer[5].nhwc(r)

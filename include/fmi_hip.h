@@ -391,6 +391,9 @@ int fmi_scale_channels_add_bf16(const uint16_t* x, const float* s, const uint16_
 int fmi_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, void* stream);
 int fmi_global_avgpool_bf16(const uint16_t* x, float* pooled, float* ws, int64_t ws_floats, int N, int64_t P, int C, void* stream);
 int fmi_add_bcast_bf16(const uint16_t* g, const float* gpool, uint16_t* gx, int N, int64_t P, int C, void* stream);
+/* fp32 twin: gx[n][p][c] = g[n][p][c] + gpool[n][c] / P -- the two gradients of an SE module's input (helpers.py:38-54: avg_pool and the
+ * gated product both read it) in one pass.  C % 4 == 0, 16-byte aligned pointers. */
+int fmi_add_bcast_f32(const float* g, const float* gpool, float* gx, int N, int64_t P, int C, void* stream);
 int fmi_subsample_bf16(const uint16_t* x, uint16_t* y, int N, int H, int W, int C, int stride, int backward, void* stream);
 /* y = x * s[n][c] + res: SE gate and residual add of a bottleneck_IR_SE block (helpers.py:64-72,116-118) in one pass (C % 4 == 0) */
 int fmi_scale_channels_add_f32(const float* x, const float* s, const float* res, float* y, int N, int64_t P, int C, void* stream);
