@@ -92,28 +92,16 @@ __host__ __device__ inline int64_t tr_tiles(int rows, int C, int taps) {
   const int cc = tr_cc(taps);
   return (int64_t)((rows + TR_R - 1) / TR_R) * ((C + cc - 1) / cc);
 }
-__global__ void __launch_bounds__(256) wp_pack_kernel(const PrepArgs args) {
-  __shared__ float tile[TR_R][TR_MAX + 1];
-  const fmi_weight_entry e = args.e[blockIdx.y];
-  const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
-  if (taps > TR_MAX) {  // no tile fits: element-wise gather
-    const int64_t total = (int64_t)rows * width;
-    const float sigma = e.u ? e.sigma[0] : 1.f;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
-      const int r = (int)(o % rows);
-      const int64_t q = o / rows;
-      const int c = (int)(q % C), tap = (int)(q / C);
-      float v = e.w[(int64_t)r * width + c * taps + tap];
-      if (e.u) v = v / sigma;
-      e.wf[o] = v;
-      if (e.wt) e.wt[((int64_t)tap * rows + r) * C + c] = v;
-    }
-    return;
-  }
-  const int cc = tr_cc(taps), ctiles = (C + cc - 1) / cc;
-  if ((int64_t)blockIdx.x >= tr_tiles(rows, C, taps)) return;
-  const int r0 = (blockIdx.x / ctiles) * TR_R, c0 = (blockIdx.x % ctiles) * cc;
-  const int cn = C - c0 < cc ? C - c0 : cc, rn = rows - r0 < TR_R ? rows - r0 : TR_R, run = cn * taps;
+// One tile of the re-layout.  TAPS_ > 0: the tap count at compile time (9 and 1 are all the networks have), FULL: a whole 32-row x
+// tr_cc-channel tile -- every index split below then divides by constants (with run-time divisors the kernel spent its time in integer
+// division: 2.2 ms per train_psp step for 24 bytes per weight, a third of what the memory system moves in that time).
+template <int TAPS_, bool FULL>
+__device__ __forceinline__ void wp_tile(const fmi_weight_entry& e, float (*tile)[TR_MAX + 1], int r0, int c0, int cn_rt, int rn_rt, int taps_rt, int cc_rt) {
+  const int rows = e.rows, C = e.C;
+  const int taps = TAPS_ > 0 ? TAPS_ : taps_rt;
+  const int cc = TAPS_ > 0 ? tr_cc(TAPS_) : cc_rt;
+  const int cn = FULL ? cc : cn_rt, rn = FULL ? TR_R : rn_rt;
+  const int width = C * taps, run = cn * taps;
   const float sigma = e.u ? e.sigma[0] : 1.f;
   for (int i = threadIdx.x; i < rn * run; i += 256) {  // w: for each row a contiguous run of cn * taps floats
     const int rl = i / run, j = i - rl * run;
@@ -162,6 +150,38 @@ __global__ void __launch_bounds__(256) wp_pack_kernel(const PrepArgs args) {
       for (int pc = 0; pc < 3; ++pc)
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(e.wt3) + pc * pstride + chunk * 8) = make_uint4(w[pc][0], w[pc][1], w[pc][2], w[pc][3]);
     }
+  }
+}
+__global__ void __launch_bounds__(256) wp_pack_kernel(const PrepArgs args) {
+  __shared__ float tile[TR_R][TR_MAX + 1];
+  const fmi_weight_entry e = args.e[blockIdx.y];
+  const int rows = e.rows, C = e.C, taps = e.taps, width = C * taps;
+  if (taps > TR_MAX) {  // no tile fits: element-wise gather
+    const int64_t total = (int64_t)rows * width;
+    const float sigma = e.u ? e.sigma[0] : 1.f;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+      const int r = (int)(o % rows);
+      const int64_t q = o / rows;
+      const int c = (int)(q % C), tap = (int)(q / C);
+      float v = e.w[(int64_t)r * width + c * taps + tap];
+      if (e.u) v = v / sigma;
+      e.wf[o] = v;
+      if (e.wt) e.wt[((int64_t)tap * rows + r) * C + c] = v;
+    }
+    return;
+  }
+  const int cc = tr_cc(taps), ctiles = (C + cc - 1) / cc;
+  if ((int64_t)blockIdx.x >= tr_tiles(rows, C, taps)) return;
+  const int r0 = (blockIdx.x / ctiles) * TR_R, c0 = (blockIdx.x % ctiles) * cc;
+  const int cn = C - c0 < cc ? C - c0 : cc, rn = rows - r0 < TR_R ? rows - r0 : TR_R, run = cn * taps;
+  if (taps == 9) {
+    if (cn == cc && rn == TR_R) wp_tile<9, true>(e, tile, r0, c0, cn, rn, taps, cc);
+    else wp_tile<9, false>(e, tile, r0, c0, cn, rn, taps, cc);
+  } else if (taps == 1) {
+    if (cn == cc && rn == TR_R) wp_tile<1, true>(e, tile, r0, c0, cn, rn, taps, cc);
+    else wp_tile<1, false>(e, tile, r0, c0, cn, rn, taps, cc);
+  } else {
+    wp_tile<0, false>(e, tile, r0, c0, cn, rn, taps, cc);
   }
 }
 
@@ -233,6 +253,26 @@ __global__ void __launch_bounds__(256) wg_dot_kernel(const GradArgs args, float*
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) atomicAdd(dots + blockIdx.y, s);
 }
+// one tile of the gradient's way back (dwf[tap][c][row] -> dw[row][c][tap]), specialised like wp_tile
+template <int TAPS_, bool FULL>
+__device__ __forceinline__ void wg_tile(const fmi_weight_grad_entry& e, float (*tile)[TR_MAX + 1], int r0, int c0, int cn_rt, int rn_rt, int taps_rt,
+                                        float sigma, float coef) {
+  const int rows = e.rows, C = e.C;
+  const int taps = TAPS_ > 0 ? TAPS_ : taps_rt;
+  const int cn = (FULL && TAPS_ > 0) ? tr_cc(TAPS_ > 0 ? TAPS_ : 1) : cn_rt, rn = FULL ? TR_R : rn_rt;
+  const int width = C * taps, run = cn * taps;
+  for (int i = threadIdx.x; i < TR_R * cn * taps; i += 256) {  // dwf[tap][c][row]: 32 consecutive rows per (tap, c)
+    const int rl = i % TR_R, q = i / TR_R, cl = q % cn, tap = q / cn;
+    if (rl < rn) tile[rl][cl * taps + tap] = e.dwf[((int64_t)tap * C + c0 + cl) * rows + r0 + rl];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rn * run; i += 256) {  // dw[row][c][tap]: a contiguous run of cn * taps floats per row
+    const int rl = i / run, j = i - rl * run;
+    float g = tile[rl][j];
+    if (e.u) g = g / sigma - coef * e.u[r0 + rl] * e.v[c0 * taps + j];
+    e.dw[(int64_t)(r0 + rl) * width + c0 * taps + j] = g;
+  }
+}
 __global__ void __launch_bounds__(256) wg_apply_kernel(const GradArgs args, const float* __restrict__ dots) {
   __shared__ float tile[TR_R][TR_MAX + 1];
   const fmi_weight_grad_entry e = args.e[blockIdx.y];
@@ -257,17 +297,15 @@ __global__ void __launch_bounds__(256) wg_apply_kernel(const GradArgs args, cons
   const int cc = tr_cc(taps), ctiles = (C + cc - 1) / cc;
   if ((int64_t)blockIdx.x >= tr_tiles(rows, C, taps)) return;
   const int r0 = (blockIdx.x / ctiles) * TR_R, c0 = (blockIdx.x % ctiles) * cc;
-  const int cn = C - c0 < cc ? C - c0 : cc, rn = rows - r0 < TR_R ? rows - r0 : TR_R, run = cn * taps;
-  for (int i = threadIdx.x; i < TR_R * cn * taps; i += 256) {  // dwf[tap][c][row]: 32 consecutive rows per (tap, c)
-    const int rl = i % TR_R, q = i / TR_R, cl = q % cn, tap = q / cn;
-    if (rl < rn) tile[rl][cl * taps + tap] = e.dwf[((int64_t)tap * C + c0 + cl) * rows + r0 + rl];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < rn * run; i += 256) {  // dw[row][c][tap]: a contiguous run of cn * taps floats per row
-    const int rl = i / run, j = i - rl * run;
-    float g = tile[rl][j];
-    if (e.u) g = g / sigma - coef * e.u[r0 + rl] * e.v[c0 * taps + j];
-    e.dw[(int64_t)(r0 + rl) * width + c0 * taps + j] = g;
+  const int cn = C - c0 < cc ? C - c0 : cc, rn = rows - r0 < TR_R ? rows - r0 : TR_R;
+  if (taps == 9) {
+    if (cn == cc && rn == TR_R) wg_tile<9, true>(e, tile, r0, c0, cn, rn, taps, sigma, coef);
+    else wg_tile<9, false>(e, tile, r0, c0, cn, rn, taps, sigma, coef);
+  } else if (taps == 1) {
+    if (cn == cc && rn == TR_R) wg_tile<1, true>(e, tile, r0, c0, cn, rn, taps, sigma, coef);
+    else wg_tile<1, false>(e, tile, r0, c0, cn, rn, taps, sigma, coef);
+  } else {
+    wg_tile<0, false>(e, tile, r0, c0, cn, rn, taps, sigma, coef);
   }
 }
 extern "C" int fmi_weight_grad_f32(const fmi_weight_grad_entry* entries, int count, float* scratch_zeroed, void* stream) {
