@@ -113,6 +113,7 @@ SIGNATURES = {
     "fmi_global_avgpool_bf16": [vp, vp, vp, i64, i32, i64, i32, vp],
     "fmi_add_bcast_bf16": [vp, vp, vp, i32, i64, i32, vp],
     "fmi_add_bcast_f32": [vp, vp, vp, i32, i64, i32, vp],
+    "fmi_scale_channels_bwd_f32": [vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, vp],
     "fmi_subsample_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "fmi_scale_channels_add_f32": [vp, vp, vp, vp, i32, i64, i32, vp],
     "fmi_instnorm_bwd_apply_add_f32": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],

@@ -126,6 +126,66 @@ extern "C" int fmi_scale_channels_gs_f32(const float* g, const float* x, float* 
   return fmi_launch_status();
 }
 
+// Both gradients of y = x * s[n][c] in ONE pass over g and x: gx = g * s (written) and gs[n][c] = sum_p g * x (row-block partials in ws,
+// then the adding launch above) -- the SE gate of every IR-SE block, the modulation / demodulation products of the fp32 decoder.  Two
+// launches read g twice, and the gs kernel used 4-byte loads (2.3 TB/s).  A thread keeps one 4-channel group; C % 4 == 0, C / 4 <= 256.
+__global__ void __launch_bounds__(256) scale_channels_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ x,
+                                                                 const float* __restrict__ s, float4* __restrict__ gx, float* __restrict__ ws,
+                                                                 int64_t P, int C4, int64_t rows_per_block) {
+  __shared__ float part[256][4];
+  const int RL = 256 / C4, cg = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const int n = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  const float4* gb = g + (int64_t)n * P * C4;
+  const float4* xb = x + (int64_t)n * P * C4;
+  float4* ob = gx + (int64_t)n * P * C4;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    const float4 sv = *reinterpret_cast<const float4*>(s + ((int64_t)n * C4 + cg) * 4);
+    auto one = [&](int64_t r, const float4 gv, const float4 xv) {
+      a[0] = fmaf(gv.x, xv.x, a[0]), a[1] = fmaf(gv.y, xv.y, a[1]), a[2] = fmaf(gv.z, xv.z, a[2]), a[3] = fmaf(gv.w, xv.w, a[3]);
+      ob[r * C4 + cg] = make_float4(gv.x * sv.x, gv.y * sv.y, gv.z * sv.z, gv.w * sv.w);
+    };
+    int64_t r = r0 + rl;
+    for (; r + RL < r1; r += 2 * RL) {  // two independent pairs of 16-byte loads in flight
+      const float4 g0 = gb[r * C4 + cg], x0 = xb[r * C4 + cg], g1 = gb[(r + RL) * C4 + cg], x1 = xb[(r + RL) * C4 + cg];
+      one(r, g0, x0);
+      one(r + RL, g1, x1);
+    }
+    for (; r < r1; r += RL) one(r, gb[r * C4 + cg], xb[r * C4 + cg]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[threadIdx.x][e] = a[e];
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {
+    float t[4] = {part[threadIdx.x][0], part[threadIdx.x][1], part[threadIdx.x][2], part[threadIdx.x][3]};
+    for (int l = 1; l < RL; ++l)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += part[l * C4 + cg][e];
+    *reinterpret_cast<float4*>(ws + ((int64_t)n * gridDim.x + blockIdx.x) * C4 * 4 + cg * 4) = make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+/* gx = g * s[n][c] and gs[n][c] = sum_p g * x in one pass (the adjoint of fmi_scale_channels_f32 / the product part of
+ * fmi_scale_channels_add_f32).  ws: >= N * C floats of scratch (more = more row blocks). */
+extern "C" int fmi_scale_channels_bwd_f32(const float* g, const float* x, const float* s, float* gx, float* gs, float* ws, int64_t ws_floats, int N,
+                                          int64_t P, int C, void* stream) {
+  if (!g || !x || !s || !gx || !gs || !ws || N <= 0 || P <= 0 || C <= 0 || N > 65535 || ws_floats < (int64_t)N * C) return FMI_ERR_BAD_ARG;
+  if (C % 4 != 0 || C / 4 > 256 || (((uintptr_t)g | (uintptr_t)x | (uintptr_t)s | (uintptr_t)gx | (uintptr_t)ws) & 15)) return FMI_ERR_UNSUPPORTED;
+  int64_t blocks = ceil_div64(P, 64);
+  int64_t cap = ws_floats / ((int64_t)N * C);
+  const int64_t want = ceil_div64(4096, N);
+  if (cap > want) cap = want;
+  if (blocks > cap) blocks = cap;
+  const int64_t rpb = ceil_div64(P, blocks);
+  blocks = ceil_div64(P, rpb);
+  hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (const float4*)x, s,
+                     (float4*)gx, ws, P, C / 4, rpb);
+  hipLaunchKernelGGL(scale_channels_gs_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, gs, (int)blocks, C, N * C);
+  return fmi_launch_status();
+}
+
 // out[r] = sum_k x[r][k]^2  and its gradient gx[r][k] = 2 x[r][k] g[r]     (W^2 summed over the taps)
 __global__ void __launch_bounds__(256) sqsum_last_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int k) {
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {

@@ -1716,6 +1716,22 @@ def linear(x, w, bias=None, alpha=1.0):
     return _Linear.apply(x.contiguous(), w.contiguous(), bias, float(alpha))
 
 
+def _scale_bwd_ok(g, x, s, c):
+    """shapes the one-pass adjoint (fmi_scale_channels_bwd_f32) takes; off with FMI_SCALE_BWD_FUSED=0 (A/B)"""
+    return (_SCALE_BWD_FUSED and g.dtype == torch.float32 and c % 4 == 0 and c <= 1024 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and
+            s.data_ptr() % 16 == 0)
+
+
+def _scale_channels_bwd(g, x, s, n, p, c):
+    gx, gs = torch.empty_like(x), torch.empty_like(s)
+    ws = _parts_ws(x.device, max(4096, n) * c)
+    _L().scale_channels_bwd_f32(_p(g), _p(x), _p(s), _p(gx), _p(gs), _p(ws), ws.numel(), n, p, c, _st())
+    return gx, gs
+
+
+_SCALE_BWD_FUSED = os.environ.get("FMI_SCALE_BWD_FUSED", "1") != "0"
+
+
 class _ScaleChannels(torch.autograd.Function):
     """y[n,p,c] = x[n,p,c] * s[n,c]"""
 
@@ -1738,6 +1754,8 @@ class _ScaleChannels(torch.autograd.Function):
         p = x.numel() // (n * c)
         gx = gs = None
         b16 = x.dtype == BF16
+        if not b16 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _scale_bwd_ok(g, x, s, c):
+            return _scale_channels_bwd(g, x, s, n, p, c)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             (_L().scale_channels_bf16 if b16 else _L().scale_channels_f32)(_p(g), _p(s), _p(gx), n, p, c, _st())
@@ -1776,6 +1794,9 @@ class _ScaleChannelsAdd(torch.autograd.Function):
         n, c = s.shape
         p = x.numel() // (n * c)
         gx = gs = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and _scale_bwd_ok(g, x, s, c):
+            gx, gs = _scale_channels_bwd(g, x, s, n, p, c)
+            return gx, gs, (g if ctx.needs_input_grad[2] else None)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             _L().scale_channels_f32(_p(g), _p(s), _p(gx), n, p, c, _st())

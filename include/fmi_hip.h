@@ -397,6 +397,11 @@ int fmi_add_bcast_f32(const float* g, const float* gpool, float* gx, int N, int6
 int fmi_subsample_bf16(const uint16_t* x, uint16_t* y, int N, int H, int W, int C, int stride, int backward, void* stream);
 /* y = x * s[n][c] + res: SE gate and residual add of a bottleneck_IR_SE block (helpers.py:64-72,116-118) in one pass (C % 4 == 0) */
 int fmi_scale_channels_add_f32(const float* x, const float* s, const float* res, float* y, int N, int64_t P, int C, void* stream);
+/* Both gradients of y = x * s[n][c] (fp32 NHWC, s [N][C]) in one pass: gx = g * s, gs[n][c] = sum_p g * x -- the SE gate of the IR-SE
+ * blocks (helpers.py:38-54 under autograd), the modulation / demodulation products (model.py:244-252).  C % 4 == 0, C <= 1024, 16-byte
+ * aligned pointers; ws: >= N * C floats of scratch. */
+int fmi_scale_channels_bwd_f32(const float* g, const float* x, const float* s, float* gx, float* gs, float* ws, int64_t ws_floats, int N,
+                               int64_t P, int C, void* stream);
 /* fmi_instnorm_bwd_apply_f32 with gx += gadd: the gradient of a second consumer of x (the identity shortcut of an IR block) joins in the
  * same pass */
 int fmi_instnorm_bwd_apply_add_f32(const float* x, const float* gy, const float* stats, const float* gamma, const float* beta,
