@@ -86,24 +86,33 @@ __device__ __forceinline__ void chunk_reduce_store(float (&acc)[8], float* __res
   __syncthreads();
 }
 // out[g][i] = sum_{p < nparts} ws[(g * nparts + p) * width + i]
-__global__ void __launch_bounds__(256) sum_parts_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width,
-                                                        int64_t total) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= total) return;
-  const int64_t g = t / width;
-  const int i = (int)(t - g * width);
-  const float* p = ws + g * nparts * (int64_t)width + i;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int q = 0;
-  for (; q + 3 < nparts; q += 4) {
-    a0 += p[(int64_t)q * width], a1 += p[(int64_t)(q + 1) * width], a2 += p[(int64_t)(q + 2) * width], a3 += p[(int64_t)(q + 3) * width];
+// 64 columns x 16 row lanes per workgroup, eight independent loads in flight per thread, the lanes' sums added in a fixed order (one
+// thread per column walking up to 512 rows with four accumulators was a latency chain: 18 us per launch, 43 launches per C5 step)
+__global__ void __launch_bounds__(1024) sum_parts_kernel(const float* __restrict__ ws, float* __restrict__ out, int nparts, int width) {
+  __shared__ float part[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  const float* p = ws + (int64_t)blockIdx.y * nparts * width + i;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < width) {
+    int q = ty;
+    for (; q + 7 * 16 < nparts; q += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += p[(int64_t)(q + 16 * u) * width];
+    }
+    for (; q < nparts; q += 16) a[0] += p[(int64_t)q * width];
   }
-  for (; q < nparts; ++q) a0 += p[(int64_t)q * width];
-  out[t] = (a0 + a1) + (a2 + a3);
+  part[ty][tx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (ty == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += part[l][tx];
+    out[(int64_t)blockIdx.y * width + i] = t;
+  }
 }
 static void launch_sum_parts(const float* ws, float* out, int nparts, int width, int64_t groups, hipStream_t st) {
-  const int64_t total = groups * width;
-  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, st, ws, out, nparts, width, total);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((width + 63) / 64), (unsigned)groups), dim3(1024), 0, st, ws, out, nparts, width);
 }
 // how many row blocks a reduction pass uses: enough to fill the chip, at most what the workspace holds (width floats per block)
 static int64_t parts_for(int64_t rows, int64_t groups, int64_t width, int64_t ws_floats) {
